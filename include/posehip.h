@@ -1,0 +1,148 @@
+/* libposehip -- C ABI of the MI355X-native OpenPose bottom-up inference path.
+ *
+ * The reference (cheneeheng/pose-estimation) is Python and reaches this path
+ * through two third-party engines, not through an FFI of its own:
+ *   - cv2.dnn:     openpose/opencv/skeleton.py:50,66-75  (readNetFromCaffe,
+ *                  blobFromImage, net.forward) + the in-tree decode
+ *                  openpose/opencv/utils.py:9-173          ("V1" decode)
+ *   - pyopenpose:  openpose/native/python/skeleton.py:424-447 (WrapperPython
+ *                  configure/start/emplaceAndPop)          ("V2" decode)
+ * Each entry point below names the reference call it stands in for.  The
+ * Python classes that keep the reference's estimator interface
+ * (pose-estimation_amd/posehip/api_opencv.py, api_native.py) bind these
+ * symbols with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions: every function returns 0 on success and a negative value on
+ * error (never throws); ph_last_error() returns the message of the calling
+ * thread's last failure.  One ph_ctx == one device + one HIP stream; a ctx is
+ * not thread-safe, distinct ctxs are independent.  "dev" pointers are device
+ * addresses (e.g. torch.Tensor.data_ptr()), "host" pointers are host memory.
+ */
+#ifndef POSEHIP_H
+#define POSEHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ph_ctx ph_ctx;
+
+#define PH_MAX_DST 8
+#define PH_OP_CONV 0
+#define PH_OP_POOL 1
+#define PH_ACT_NONE 0
+#define PH_ACT_RELU 1
+#define PH_ACT_PRELU 2
+#define PH_PRE_CV2 0    /* blobFromImage(1/255, size, mean 0, no crop)           */
+#define PH_PRE_NATIVE 1 /* OpenPose cvMatToOpInput: keep-aspect, x/256 - 0.5     */
+
+/* A zero-bordered NHWC bf16 activation buffer [B][H+2*pad][W+2*pad][channels]. */
+typedef struct {
+  int channels; /* channel stride, multiple of 8 */
+  int height, width;
+  int pad;      /* border width (>= max pad of its consumer convs) */
+} ph_buf_desc;
+
+/* One fused operation of the execution plan (built by posehip/graph.py from the
+ * Caffe prototxt the reference hands to readNetFromCaffe / OpenPose). */
+typedef struct {
+  int type;                 /* PH_OP_CONV | PH_OP_POOL */
+  int in_buf, in_coff;      /* input buffer id, first channel read */
+  int cin_read;             /* channels read (multiple of 8) */
+  int kh, kw;               /* odd kernel, stride 1, pad = (k-1)/2 ("same") */
+  int cout;
+  int act;                  /* PH_ACT_* fused after bias */
+  int n_dst;
+  int dst_buf[PH_MAX_DST];
+  int dst_coff[PH_MAX_DST]; /* multiples of 8 */
+  int f32_coff;             /* >=0: also write fp32 into net_out channel f32_coff.. */
+  int cin_caffe;            /* input channels of the Caffe weight blob */
+  int slope_count;          /* 1 (channel_shared) or cout */
+  int tile_n;               /* 0 = auto; else 32/64/96/128 */
+  const float* weight;      /* host [cout][cin_caffe][kh][kw] */
+  const float* bias;        /* host [cout] or NULL */
+  const float* slope;       /* host PReLU slopes or NULL */
+  const int32_t* cin_map;   /* host [cin_read]: caffe input channel or -1 (zero) */
+} ph_op_desc;
+
+/* Upstream-OpenPose decode constants ("V2"; posehip/tables.py PoseModelV2). */
+typedef struct {
+  int n_parts;        /* 25 (BODY_25) / 18 (COCO): NMS runs on channels [0,n_parts) */
+  int n_heat;         /* n_parts + 1 (background): first PAF channel */
+  int n_pairs;
+  int max_peaks;      /* 127 */
+  int ear_pair0, ear_pair1;
+  int min_subset_cnt;
+  float nms_threshold, inter_threshold, inter_min_above_threshold, min_subset_score;
+  int pairs[64 * 2];  /* limb (partA, partB) */
+  int mapidx[64 * 2]; /* PAF channel pair per limb, relative to n_heat */
+} ph_v2_model;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+/* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to
+ * create a private one.  Stands in for cv2.dnn.readNetFromCaffe's Net object /
+ * op.WrapperPython() (opencv/skeleton.py:50; native/python/skeleton.py:424). */
+int ph_create(ph_ctx** out, int device, void* stream);
+void ph_destroy(ph_ctx* ctx);
+int ph_sync(ph_ctx* ctx);
+const char* ph_last_error(void);
+/* 1 when the library was built for the device it runs on (gfx950). */
+int ph_device_ok(int device);
+
+/* ---- network (replaces net.setInput/net.forward, opencv/skeleton.py:74-75;
+ *      the Caffe forward inside emplaceAndPop, native/python/skeleton.py:447) */
+int ph_net_build(ph_ctx* ctx, int batch, const ph_buf_desc* bufs, int n_bufs, const ph_op_desc* ops, int n_ops,
+                 int out_channels, int out_h, int out_w);
+/* frames: u8 [B][H0][W0][3] BGR, host (on_device=0) or device memory.
+ * Replaces cv2.dnn.blobFromImage (opencv/skeleton.py:66-73) / cvMatToOpInput. */
+int ph_preprocess(ph_ctx* ctx, const uint8_t* frames, int on_device, int B, int H0, int W0, int mode);
+int ph_forward(ph_ctx* ctx, int B);
+/* forward with a HIP event recorded on the ctx stream around every op.  ms (n_ops
+ * slots, device time per op) may be NULL: then nothing is waited for and
+ * ph_forward_times() reads the last timed forward's durations later. */
+int ph_forward_timed(ph_ctx* ctx, int B, float* ms);
+int ph_forward_times(ph_ctx* ctx, float* ms);
+/* algorithmic FLOPs of op i for one frame (2*K*K*Cin*Cout*H*W, unpadded) */
+double ph_op_flops(ph_ctx* ctx, int op);
+/* net output, fp32 NCHW [B][C][Hs][Ws] (what predict() returns, opencv/skeleton.py:75) */
+int ph_get_net_out(ph_ctx* ctx, int B, float* host_out);
+float* ph_net_out_dev(ph_ctx* ctx);
+/* inject a net output (predict_from_hm, native/python/skeleton.py:469-481) */
+int ph_set_net_out(ph_ctx* ctx, const float* src, int on_device, int B, int C, int Hs, int Ws);
+/* debug/test: copy an activation buffer (bf16 bits) to host */
+int ph_get_buffer(ph_ctx* ctx, int buf, uint16_t* host_out, int64_t n_elems);
+
+/* ---- V2 decode (replaces OpenPose resizeAndMerge + nms + bodyPartConnector
+ *      inside emplaceAndPop, native/python/skeleton.py:447) ------------------
+ * Decodes the ctx's net output for B frames at target resolution Ht x Wt
+ * (bicubic upsample never materialised).  Host outputs, caller-allocated:
+ *   n_people   int32 [B]            people found (may exceed max_people)
+ *   keypoints  f32   [B][max_people][n_parts][3]
+ *   scores     f32   [B][max_people]
+ *   peaks      f32   [B][n_parts][max_peaks+1][3]   (optional, may be NULL)
+ *   subsets    int32 [B][max_people][n_parts+1]     (optional, may be NULL)
+ * scale: keypoint x,y multiplier (net-input -> image pixels). */
+int ph_decode_v2(ph_ctx* ctx, const ph_v2_model* model, int B, int Ht, int Wt, float scale, int max_people,
+                 int32_t* n_people, float* keypoints, float* scores, float* peaks, int32_t* subsets);
+/* same, but leaves results in device memory for a later RCCL gather; the
+ * returned pointers stay valid until the next decode on this ctx */
+int ph_decode_v2_dev(ph_ctx* ctx, const ph_v2_model* model, int B, int Ht, int Wt, float scale, int max_people,
+                     int32_t** n_people_dev, float** keypoints_dev, float** scores_dev);
+/* asynchronous copy (on the ctx stream, no wait) of the last ph_decode_v2_dev
+ * results into caller buffers of the shapes above: pinned host memory
+ * (dst_on_device=0) or device memory (dst_on_device=1, e.g. the send buffer of
+ * the RCCL keypoint gather).  Any pointer may be NULL. */
+int ph_decode_v2_results(ph_ctx* ctx, int32_t* n_people, float* keypoints, float* scores, int dst_on_device);
+/* test/debug: per-limb connections of the last decode.  n_conn i32 [B][n_pairs],
+ * conn_idx i32 [B][n_pairs][max_peaks][2] (upstream peak indices part*3*(max_peaks+1)
+ * + i*3 + 2), conn_score f32 [B][n_pairs][max_peaks]; any pointer may be NULL. */
+int ph_decode_v2_connections(ph_ctx* ctx, int32_t* n_conn, int32_t* conn_idx, float* conn_score);
+/* device time (ms) of the decode kernels of the last ph_decode_v2* call:
+ * [0] upsample+NMS, [1] PAF scoring+matching, [2] assembly */
+int ph_decode_v2_times(ph_ctx* ctx, float* ms3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,618 @@
+// C ABI of libposehip (declared in include/posehip.h): context, network plan
+// execution, decode entry points.  Host-side only; kernels live in
+// conv_mfma.hip / preprocess.hip / decode_v2.hip.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/posehip.h"
+#include "common.h"
+#include "decode_v2.h"
+
+int ph_launch_conv(const PhConvParams& p, int nrep, hipStream_t stream);
+int ph_launch_maxpool(const bf16* in, bf16* out, int B, int H, int W, int C, int in_Hp, int in_Wp, int in_Cs,
+                      int in_org, int oH, int oW, int out_Hp, int out_Wp, int out_Cs, int out_org,
+                      hipStream_t stream);
+int ph_launch_preprocess(const uint8_t* frames, int B, int H0, int W0, int Hn, int Wn, int mode, bf16* out,
+                         int out_Hp, int out_Wp, int out_Cs, int out_org, hipStream_t stream);
+
+static thread_local char g_err[1024] = "";
+
+void ph_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct Buf {
+  ph_buf_desc d;
+  bf16* ptr = nullptr;
+  size_t elems = 0;
+  int Hp() const { return d.height + 2 * d.pad; }
+  int Wp() const { return d.width + 2 * d.pad; }
+  // element offset of interior pixel (0,0), shifted by (dy,dx) pixels, channel c
+  int org(int shift, int c) const { return ((d.pad + shift) * Wp() + d.pad + shift) * d.channels + c; }
+};
+
+struct Op {
+  ph_op_desc d;
+  PhConvParams cp;   // conv: device-ready parameters (B-dependent fields patched per call)
+  int nrep = 0;
+  bf16* wt = nullptr;
+  float* bias = nullptr;
+  float* slope = nullptr;
+  double flops = 0.0;  // algorithmic, per frame
+};
+
+struct ph_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int batch = 0;
+  std::vector<Buf> bufs;
+  std::vector<Op> ops;
+  int out_c = 0, out_h = 0, out_w = 0;
+  float* net_out = nullptr;
+  size_t net_out_elems = 0;
+  // injected net output geometry (ph_set_net_out) or the built network's
+  int cur_c = 0, cur_h = 0, cur_w = 0;
+  uint8_t* frames = nullptr;
+  size_t frames_bytes = 0;
+  // decode workspace
+  PhV2Buffers v2 = {};
+  PhV2Sizes v2sz = {};
+  size_t v2_key = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> op_ev;
+};
+
+static uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+extern "C" {
+
+const char* ph_last_error(void) { return g_err; }
+
+int ph_device_ok(int device) {
+  hipDeviceProp_t prop;
+  PH_CHECK(hipGetDeviceProperties(&prop, device));
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int ph_create(ph_ctx** out, int device, void* stream) {
+  if (!out) {
+    ph_set_error("ph_create: null out");
+    return -1;
+  }
+  int n = 0;
+  PH_CHECK(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) {
+    ph_set_error("ph_create: device %d out of range (%d visible)", device, n);
+    return -1;
+  }
+  PH_CHECK(hipSetDevice(device));
+  const int ok = ph_device_ok(device);
+  if (ok < 0) return -1;
+  if (!ok) {
+    ph_set_error("ph_create: device %d is not gfx950 (libposehip is built for MI355X only)", device);
+    return -1;
+  }
+  ph_ctx* c = new ph_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    PH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  for (int i = 0; i < 4; i++) PH_CHECK(hipEventCreate(&c->ev[i]));
+  *out = c;
+  return 0;
+}
+
+static void free_net(ph_ctx* c) {
+  for (auto& b : c->bufs)
+    if (b.ptr) (void)hipFree(b.ptr);
+  for (auto& o : c->ops) {
+    if (o.wt) (void)hipFree(o.wt);
+    if (o.bias) (void)hipFree(o.bias);
+    if (o.slope) (void)hipFree(o.slope);
+  }
+  c->bufs.clear();
+  c->ops.clear();
+  for (auto e : c->op_ev) (void)hipEventDestroy(e);
+  c->op_ev.clear();
+}
+
+static void free_v2(ph_ctx* c) {
+  void* ptrs[] = {c->v2.peaks,    c->v2.pair_scores, c->v2.conn_idx, c->v2.conn_score, c->v2.n_conn,
+                  c->v2.n_people, c->v2.keypoints,   c->v2.scores,   c->v2.subsets,    c->v2.overflow};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  c->v2 = PhV2Buffers{};
+  c->v2_key = 0;
+}
+
+void ph_destroy(ph_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_net(c);
+  free_v2(c);
+  if (c->net_out) (void)hipFree(c->net_out);
+  if (c->frames) (void)hipFree(c->frames);
+  for (int i = 0; i < 4; i++)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int ph_sync(ph_ctx* c) {
+  PH_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int ensure_net_out(ph_ctx* c, size_t elems) {
+  if (elems > c->net_out_elems) {
+    if (c->net_out) PH_CHECK(hipFree(c->net_out));
+    c->net_out = nullptr;
+    PH_CHECK(hipMalloc(&c->net_out, elems * sizeof(float)));
+    c->net_out_elems = elems;
+  }
+  return 0;
+}
+
+static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, const ph_op_desc* ops, int n_ops,
+                     int out_channels, int out_h, int out_w);
+
+int ph_net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, const ph_op_desc* ops, int n_ops,
+                 int out_channels, int out_h, int out_w) {
+  const int rc = net_build(c, batch, bufs, n_bufs, ops, n_ops, out_channels, out_h, out_w);
+  if (rc) {  // never leave a half-built plan behind
+    (void)hipStreamSynchronize(c->stream);
+    free_net(c);
+    c->batch = 0;
+  }
+  return rc;
+}
+
+static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, const ph_op_desc* ops, int n_ops,
+                     int out_channels, int out_h, int out_w) {
+  PH_CHECK(hipSetDevice(c->device));
+  PH_CHECK(hipStreamSynchronize(c->stream));
+  free_net(c);
+  if (batch < 1 || n_bufs < 1 || n_ops < 1) {
+    ph_set_error("ph_net_build: bad sizes (batch %d, %d buffers, %d ops)", batch, n_bufs, n_ops);
+    return -1;
+  }
+  c->batch = batch;
+  c->out_c = out_channels;
+  c->out_h = out_h;
+  c->out_w = out_w;
+  c->bufs.resize(n_bufs);
+  for (int i = 0; i < n_bufs; i++) {
+    Buf& b = c->bufs[i];
+    b.d = bufs[i];
+    if (b.d.channels % 8 || b.d.channels < 8 || b.d.height < 1 || b.d.width < 1 || b.d.pad < 0) {
+      ph_set_error("ph_net_build: buffer %d: channels %d must be a positive multiple of 8", i, b.d.channels);
+      return -1;
+    }
+    b.elems = (size_t)batch * b.Hp() * b.Wp() * b.d.channels;
+    if (b.elems >= 0xffffffffull) {
+      ph_set_error("ph_net_build: buffer %d has %zu elements; 32-bit offsets need < 2^32", i, b.elems);
+      return -1;
+    }
+    PH_CHECK(hipMalloc(&b.ptr, b.elems * sizeof(bf16)));
+    PH_CHECK(hipMemsetAsync(b.ptr, 0, b.elems * sizeof(bf16), c->stream));  // zero border, zero pad channels
+  }
+  if (ensure_net_out(c, (size_t)batch * out_channels * out_h * out_w)) return -1;
+  PH_CHECK(hipMemsetAsync(c->net_out, 0, c->net_out_elems * sizeof(float), c->stream));
+  c->ops.resize(n_ops);
+  for (int i = 0; i < n_ops; i++) {
+    Op& o = c->ops[i];
+    o.d = ops[i];
+    const ph_op_desc& d = o.d;
+    if (d.in_buf < 0 || d.in_buf >= n_bufs || d.n_dst < 0 || d.n_dst > PH_MAX_DST) {
+      ph_set_error("ph_net_build: op %d: bad buffer ids", i);
+      return -1;
+    }
+    const Buf& in = c->bufs[d.in_buf];
+    for (int k = 0; k < d.n_dst; k++)
+      if (d.dst_buf[k] < 0 || d.dst_buf[k] >= n_bufs) {
+        ph_set_error("ph_net_build: op %d: bad dst buffer", i);
+        return -1;
+      }
+    if (d.type == PH_OP_POOL) {
+      if (d.n_dst != 1) {
+        ph_set_error("ph_net_build: op %d: pool needs exactly one dst", i);
+        return -1;
+      }
+      const Buf& ob = c->bufs[d.dst_buf[0]];
+      if (ob.d.channels != in.d.channels || ob.d.height != (in.d.height + 1) / 2 ||
+          ob.d.width != (in.d.width + 1) / 2) {
+        ph_set_error("ph_net_build: op %d: pool geometry mismatch", i);
+        return -1;
+      }
+      continue;
+    }
+    if (d.type != PH_OP_CONV) {
+      ph_set_error("ph_net_build: op %d: unknown type %d", i, d.type);
+      return -1;
+    }
+    const int pad = (d.kh - 1) / 2;
+    if (d.kh != d.kw || d.kh % 2 == 0 || pad > in.d.pad) {
+      ph_set_error("ph_net_build: op %d: kernel %dx%d needs odd square kernel and input border >= %d (has %d)", i,
+                   d.kh, d.kw, pad, in.d.pad);
+      return -1;
+    }
+    if (d.cin_read % 8 || d.in_coff % 8 || d.in_coff + d.cin_read > in.d.channels || d.cin_read < 8 ||
+        !d.weight || !d.cin_map || d.cout < 1) {
+      ph_set_error("ph_net_build: op %d: bad channel window (coff %d, read %d of %d)", i, d.in_coff, d.cin_read,
+                   in.d.channels);
+      return -1;
+    }
+    for (int k = 0; k < d.n_dst; k++) {
+      const Buf& ob = c->bufs[d.dst_buf[k]];
+      if (ob.d.height != in.d.height || ob.d.width != in.d.width || d.dst_coff[k] % 8 ||
+          d.dst_coff[k] + d.cout > ob.d.channels) {
+        ph_set_error("ph_net_build: op %d: dst %d geometry/channel window mismatch", i, k);
+        return -1;
+      }
+    }
+    if (d.f32_coff >= 0 && (in.d.height != out_h || in.d.width != out_w || d.f32_coff + d.cout > out_channels)) {
+      ph_set_error("ph_net_build: op %d: fp32 output window mismatch", i);
+      return -1;
+    }
+    // tile width along Cout
+    int tn = d.tile_n;
+    if (tn == 0) tn = d.cout <= 32 ? 32 : (d.cout <= 64 ? 64 : (d.cout % 128 == 0 ? 128 : (d.cout % 96 == 0 ? 96 : 128)));
+    if (tn != 32 && tn != 64 && tn != 96 && tn != 128) {
+      ph_set_error("ph_net_build: op %d: tile_n %d not in {32,64,96,128}", i, tn);
+      return -1;
+    }
+    o.nrep = tn / 32;
+    const int cout_pad = (d.cout + tn - 1) / tn * tn;
+    const int K = d.kh * d.kw * d.cin_read;
+    const int Kpad = (K + 63) / 64 * 64;
+    if ((unsigned long long)Kpad * d.cin_read >= 0xffffffffull) {
+      ph_set_error("ph_net_build: op %d: K too large", i);
+      return -1;
+    }
+    // weights -> bf16 [cout_pad][Kpad], k = (kh*KW + kw)*cin_read + c
+    std::vector<uint16_t> w((size_t)cout_pad * Kpad, 0);
+    for (int n = 0; n < d.cout; n++)
+      for (int t = 0; t < d.kh * d.kw; t++)
+        for (int cc = 0; cc < d.cin_read; cc++) {
+          const int src = d.cin_map[cc];
+          if (src < 0) continue;
+          if (src >= d.cin_caffe) {
+            ph_set_error("ph_net_build: op %d: cin_map[%d]=%d out of range %d", i, cc, src, d.cin_caffe);
+            return -1;
+          }
+          w[(size_t)n * Kpad + t * d.cin_read + cc] =
+              f32_to_bf16(d.weight[((size_t)n * d.cin_caffe + src) * d.kh * d.kw + t]);
+        }
+    std::vector<float> bias(cout_pad, 0.f), slope(cout_pad, 0.f);
+    if (d.bias) memcpy(bias.data(), d.bias, d.cout * sizeof(float));
+    if (d.act == PH_ACT_PRELU) {
+      if (!d.slope || (d.slope_count != 1 && d.slope_count != d.cout)) {
+        ph_set_error("ph_net_build: op %d: PReLU needs 1 or cout slopes", i);
+        return -1;
+      }
+      for (int n = 0; n < d.cout; n++) slope[n] = d.slope[d.slope_count == 1 ? 0 : n];
+    }
+    PH_CHECK(hipMalloc(&o.wt, w.size() * 2));
+    PH_CHECK(hipMalloc(&o.bias, cout_pad * sizeof(float)));
+    PH_CHECK(hipMalloc(&o.slope, cout_pad * sizeof(float)));
+    PH_CHECK(hipMemcpy(o.wt, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    PH_CHECK(hipMemcpy(o.bias, bias.data(), cout_pad * sizeof(float), hipMemcpyHostToDevice));
+    PH_CHECK(hipMemcpy(o.slope, slope.data(), cout_pad * sizeof(float), hipMemcpyHostToDevice));
+    PhConvParams& p = o.cp;
+    memset(&p, 0, sizeof(p));
+    p.in = in.ptr;
+    p.wt = o.wt;
+    p.bias = o.bias;
+    p.slope = o.slope;
+    p.H = in.d.height;
+    p.W = in.d.width;
+    p.in_Hp = in.Hp();
+    p.in_Wp = in.Wp();
+    p.in_Cs = in.d.channels;
+    p.in_org = in.org(-pad, d.in_coff);
+    p.cin_read = d.cin_read;
+    p.KW = d.kw;
+    p.K = K;
+    p.Kpad = Kpad;
+    p.nk = Kpad / 64;
+    p.magic_cin = ph_magic(d.cin_read);
+    p.magic_kw = ph_magic(d.kw);
+    p.cout = d.cout;
+    p.act = d.act;
+    p.n_dst = d.n_dst;
+    for (int k = 0; k < d.n_dst; k++) {
+      const Buf& ob = c->bufs[d.dst_buf[k]];
+      p.dst[k].base = ob.ptr;
+      p.dst[k].Hp = ob.Hp();
+      p.dst[k].Wp = ob.Wp();
+      p.dst[k].Cs = ob.d.channels;
+      p.dst[k].org = ob.org(0, d.dst_coff[k]);
+    }
+    p.f32_out = d.f32_coff >= 0 ? c->net_out : nullptr;
+    p.f32_C = out_channels;
+    p.f32_coff = d.f32_coff >= 0 ? d.f32_coff : 0;
+    int real_cin = 0;
+    for (int cc = 0; cc < d.cin_read; cc++) real_cin += d.cin_map[cc] >= 0;
+    o.flops = 2.0 * d.kh * d.kw * real_cin * d.cout * in.d.height * in.d.width;
+    // descriptor pointers are host memory owned by the caller: do not keep them
+    o.d.weight = nullptr;
+    o.d.bias = nullptr;
+    o.d.slope = nullptr;
+    o.d.cin_map = nullptr;
+  }
+  c->op_ev.resize(n_ops + 1);
+  for (auto& e : c->op_ev) PH_CHECK(hipEventCreate(&e));
+  c->cur_c = out_channels;
+  c->cur_h = out_h;
+  c->cur_w = out_w;
+  PH_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int ph_preprocess(ph_ctx* c, const uint8_t* frames, int on_device, int B, int H0, int W0, int mode) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (c->bufs.empty() || B < 1 || B > c->batch || H0 < 1 || W0 < 1 || (mode != 0 && mode != 1)) {
+    ph_set_error("ph_preprocess: no network built, or bad args (B %d of %d, %dx%d, mode %d)", B, c->batch, H0, W0,
+                 mode);
+    return -1;
+  }
+  const uint8_t* src = frames;
+  const size_t bytes = (size_t)B * H0 * W0 * 3;
+  if (!on_device) {
+    if (bytes > c->frames_bytes) {
+      if (c->frames) PH_CHECK(hipFree(c->frames));
+      c->frames = nullptr;
+      PH_CHECK(hipMalloc(&c->frames, bytes));
+      c->frames_bytes = bytes;
+    }
+    PH_CHECK(hipMemcpyAsync(c->frames, frames, bytes, hipMemcpyHostToDevice, c->stream));
+    src = c->frames;
+  }
+  const Buf& b0 = c->bufs[0];
+  return ph_launch_preprocess(src, B, H0, W0, b0.d.height, b0.d.width, mode, b0.ptr, b0.Hp(), b0.Wp(),
+                              b0.d.channels, b0.org(0, 0), c->stream);
+}
+
+static int run_ops(ph_ctx* c, int B, bool timed) {
+  if (c->ops.empty() || B < 1 || B > c->batch) {
+    ph_set_error("ph_forward: no network built or batch %d outside [1,%d]", B, c->batch);
+    return -1;
+  }
+  PH_CHECK(hipSetDevice(c->device));
+  for (size_t i = 0; i < c->ops.size(); i++) {
+    Op& o = c->ops[i];
+    if (timed) PH_CHECK(hipEventRecord(c->op_ev[i], c->stream));
+    const Buf& in = c->bufs[o.d.in_buf];
+    if (o.d.type == PH_OP_POOL) {
+      const Buf& ob = c->bufs[o.d.dst_buf[0]];
+      if (ph_launch_maxpool(in.ptr, ob.ptr, B, in.d.height, in.d.width, in.d.channels, in.Hp(), in.Wp(),
+                            in.d.channels, in.org(0, 0), ob.d.height, ob.d.width, ob.Hp(), ob.Wp(), ob.d.channels,
+                            ob.org(0, 0), c->stream))
+        return -1;
+    } else {
+      o.cp.B = B;
+      o.cp.M = B * o.cp.H * o.cp.W;
+      if (ph_launch_conv(o.cp, o.nrep, c->stream)) return -1;
+    }
+  }
+  if (timed) PH_CHECK(hipEventRecord(c->op_ev[c->ops.size()], c->stream));
+  c->cur_c = c->out_c;
+  c->cur_h = c->out_h;
+  c->cur_w = c->out_w;
+  return 0;
+}
+
+int ph_forward(ph_ctx* c, int B) { return run_ops(c, B, false); }
+
+int ph_forward_times(ph_ctx* c, float* ms);
+
+int ph_forward_timed(ph_ctx* c, int B, float* ms) {
+  if (run_ops(c, B, true)) return -1;
+  return ms ? ph_forward_times(c, ms) : 0;
+}
+
+int ph_forward_times(ph_ctx* c, float* ms) {
+  if (c->ops.empty() || !ms) {
+    ph_set_error("ph_forward_times: no network built");
+    return -1;
+  }
+  PH_CHECK(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < c->ops.size(); i++) PH_CHECK(hipEventElapsedTime(&ms[i], c->op_ev[i], c->op_ev[i + 1]));
+  return 0;
+}
+
+double ph_op_flops(ph_ctx* c, int op) {
+  if (op < 0 || op >= (int)c->ops.size()) return -1.0;
+  return c->ops[op].flops;
+}
+
+int ph_get_net_out(ph_ctx* c, int B, float* host_out) {
+  PH_CHECK(hipSetDevice(c->device));
+  const size_t n = (size_t)B * c->cur_c * c->cur_h * c->cur_w;
+  if (!c->net_out || n > c->net_out_elems) {
+    ph_set_error("ph_get_net_out: no net output for batch %d", B);
+    return -1;
+  }
+  PH_CHECK(hipMemcpyAsync(host_out, c->net_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  PH_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+float* ph_net_out_dev(ph_ctx* c) { return c->net_out; }
+
+int ph_set_net_out(ph_ctx* c, const float* src, int on_device, int B, int C, int Hs, int Ws) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (B < 1 || C < 1 || Hs < 1 || Ws < 1 || !src) {
+    ph_set_error("ph_set_net_out: bad shape [%d,%d,%d,%d]", B, C, Hs, Ws);
+    return -1;
+  }
+  const size_t n = (size_t)B * C * Hs * Ws;
+  if (!c->ops.empty() && n > c->net_out_elems) {
+    ph_set_error("ph_set_net_out: %zu elements exceed the built network's output (%zu)", n, c->net_out_elems);
+    return -1;  // conv epilogues hold the pointer; do not reallocate under them
+  }
+  if (ensure_net_out(c, n)) return -1;
+  PH_CHECK(hipMemcpyAsync(c->net_out, src, n * sizeof(float),
+                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  if (!on_device) PH_CHECK(hipStreamSynchronize(c->stream));
+  c->cur_c = C;
+  c->cur_h = Hs;
+  c->cur_w = Ws;
+  if (B > c->batch) c->batch = c->ops.empty() ? B : c->batch;
+  return 0;
+}
+
+int ph_get_buffer(ph_ctx* c, int buf, uint16_t* host_out, int64_t n_elems) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (buf < 0 || buf >= (int)c->bufs.size() || n_elems < 0 || (size_t)n_elems > c->bufs[buf].elems) {
+    ph_set_error("ph_get_buffer: bad buffer %d / size", buf);
+    return -1;
+  }
+  PH_CHECK(hipMemcpyAsync(host_out, c->bufs[buf].ptr, (size_t)n_elems * 2, hipMemcpyDeviceToHost, c->stream));
+  PH_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- V2 decode ---------------------------------------------------------------
+static int v2_prepare(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, int max_people, PhV2Dev* dev) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!m || B < 1 || max_people < 1 || !c->net_out) {
+    ph_set_error("ph_decode_v2: bad args or no net output");
+    return -1;
+  }
+  if ((size_t)B * c->cur_c * c->cur_h * c->cur_w > c->net_out_elems) {
+    ph_set_error("ph_decode_v2: batch %d exceeds the resident net output", B);
+    return -1;
+  }
+  if (m->n_pairs > 64 || m->n_pairs < 1 || m->n_parts < 1 || m->max_peaks < 1 || m->max_peaks > 1023) {
+    ph_set_error("ph_decode_v2: bad model constants");
+    return -1;
+  }
+  for (int k = 0; k < 2 * m->n_pairs; k++)
+    if (m->pairs[k] < 0 || m->pairs[k] >= m->n_parts || m->mapidx[k] < 0 ||
+        m->n_heat + m->mapidx[k] >= c->cur_c) {
+      ph_set_error("ph_decode_v2: pair/mapidx table entry %d out of range", k);
+      return -1;
+    }
+  memset(dev, 0, sizeof(*dev));
+  dev->n_parts = m->n_parts;
+  dev->n_heat = m->n_heat;
+  dev->n_pairs = m->n_pairs;
+  dev->max_peaks = m->max_peaks;
+  dev->ear_pair0 = m->ear_pair0;
+  dev->ear_pair1 = m->ear_pair1;
+  dev->min_subset_cnt = m->min_subset_cnt;
+  dev->nms_threshold = m->nms_threshold;
+  dev->inter_threshold = m->inter_threshold;
+  dev->inter_min_above = m->inter_min_above_threshold;
+  dev->min_subset_score = m->min_subset_score;
+  dev->close_score = (float)((double)m->nms_threshold + 1e-6);
+  dev->close_thr = sqrt((double)(Wt * Ht)) / 150.0;
+  memcpy(dev->pairs, m->pairs, sizeof(int) * 2 * m->n_pairs);
+  memcpy(dev->mapidx, m->mapidx, sizeof(int) * 2 * m->n_pairs);
+  const size_t key = ((size_t)B << 40) ^ ((size_t)max_people << 24) ^ ((size_t)m->n_parts << 16) ^
+                     ((size_t)m->n_pairs << 8) ^ (size_t)m->max_peaks;
+  if (key != c->v2_key) {
+    PH_CHECK(hipStreamSynchronize(c->stream));
+    free_v2(c);
+    ph_v2_workspace_sizes(*dev, B, max_people, &c->v2sz);
+    PH_CHECK(hipMalloc(&c->v2.peaks, c->v2sz.peaks));
+    PH_CHECK(hipMalloc(&c->v2.pair_scores, c->v2sz.pair_scores));
+    PH_CHECK(hipMalloc(&c->v2.conn_idx, c->v2sz.conn_idx));
+    PH_CHECK(hipMalloc(&c->v2.conn_score, c->v2sz.conn_score));
+    PH_CHECK(hipMalloc(&c->v2.n_conn, c->v2sz.n_conn));
+    PH_CHECK(hipMalloc(&c->v2.n_people, c->v2sz.n_people));
+    PH_CHECK(hipMalloc(&c->v2.keypoints, c->v2sz.keypoints));
+    PH_CHECK(hipMalloc(&c->v2.scores, c->v2sz.scores));
+    PH_CHECK(hipMalloc(&c->v2.subsets, c->v2sz.subsets));
+    PH_CHECK(hipMalloc(&c->v2.overflow, sizeof(int)));
+    c->v2_key = key;
+  }
+  return 0;
+}
+
+int ph_decode_v2_dev(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, float scale, int max_people,
+                     int32_t** n_people_dev, float** keypoints_dev, float** scores_dev) {
+  PhV2Dev dev;
+  if (v2_prepare(c, m, B, Ht, Wt, max_people, &dev)) return -1;
+  if (ph_launch_decode_v2(c->net_out, c->cur_c, c->cur_h, c->cur_w, Ht, Wt, dev, B, scale, max_people, c->v2,
+                          c->stream, c->ev))
+    return -1;
+  if (n_people_dev) *n_people_dev = c->v2.n_people;
+  if (keypoints_dev) *keypoints_dev = c->v2.keypoints;
+  if (scores_dev) *scores_dev = c->v2.scores;
+  return 0;
+}
+
+int ph_decode_v2(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, float scale, int max_people,
+                 int32_t* n_people, float* keypoints, float* scores, float* peaks, int32_t* subsets) {
+  if (ph_decode_v2_dev(c, m, B, Ht, Wt, scale, max_people, nullptr, nullptr, nullptr)) return -1;
+  hipStream_t s = c->stream;
+  if (n_people) PH_CHECK(hipMemcpyAsync(n_people, c->v2.n_people, c->v2sz.n_people, hipMemcpyDeviceToHost, s));
+  if (keypoints) PH_CHECK(hipMemcpyAsync(keypoints, c->v2.keypoints, c->v2sz.keypoints, hipMemcpyDeviceToHost, s));
+  if (scores) PH_CHECK(hipMemcpyAsync(scores, c->v2.scores, c->v2sz.scores, hipMemcpyDeviceToHost, s));
+  if (peaks) PH_CHECK(hipMemcpyAsync(peaks, c->v2.peaks, c->v2sz.peaks, hipMemcpyDeviceToHost, s));
+  if (subsets) PH_CHECK(hipMemcpyAsync(subsets, c->v2.subsets, c->v2sz.subsets, hipMemcpyDeviceToHost, s));
+  int overflow = 0;
+  PH_CHECK(hipMemcpyAsync(&overflow, c->v2.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+  PH_CHECK(hipStreamSynchronize(s));
+  if (overflow) {
+    ph_set_error("ph_decode_v2: person-candidate table overflowed (more than 2048 partial skeletons in a frame)");
+    return -2;
+  }
+  return 0;
+}
+
+int ph_decode_v2_results(ph_ctx* c, int32_t* n_people, float* keypoints, float* scores, int dst_on_device) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!c->v2.n_people) {
+    ph_set_error("ph_decode_v2_results: no decode has run");
+    return -1;
+  }
+  const hipMemcpyKind k = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  hipStream_t s = c->stream;
+  if (n_people) PH_CHECK(hipMemcpyAsync(n_people, c->v2.n_people, c->v2sz.n_people, k, s));
+  if (keypoints) PH_CHECK(hipMemcpyAsync(keypoints, c->v2.keypoints, c->v2sz.keypoints, k, s));
+  if (scores) PH_CHECK(hipMemcpyAsync(scores, c->v2.scores, c->v2sz.scores, k, s));
+  return 0;
+}
+
+int ph_decode_v2_connections(ph_ctx* c, int32_t* n_conn, int32_t* conn_idx, float* conn_score) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!c->v2.n_conn) {
+    ph_set_error("ph_decode_v2_connections: no decode has run");
+    return -1;
+  }
+  hipStream_t s = c->stream;
+  if (n_conn) PH_CHECK(hipMemcpyAsync(n_conn, c->v2.n_conn, c->v2sz.n_conn, hipMemcpyDeviceToHost, s));
+  if (conn_idx) PH_CHECK(hipMemcpyAsync(conn_idx, c->v2.conn_idx, c->v2sz.conn_idx, hipMemcpyDeviceToHost, s));
+  if (conn_score) PH_CHECK(hipMemcpyAsync(conn_score, c->v2.conn_score, c->v2sz.conn_score, hipMemcpyDeviceToHost, s));
+  PH_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int ph_decode_v2_times(ph_ctx* c, float* ms3) {
+  PH_CHECK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 3; i++) PH_CHECK(hipEventElapsedTime(&ms3[i], c->ev[i], c->ev[i + 1]));
+  return 0;
+}
+
+}  // extern "C"

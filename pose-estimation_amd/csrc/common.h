@@ -1,0 +1,58 @@
+// Shared device/host definitions for libposehip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define PH_MAX_DST 8
+
+// One bf16 NHWC destination of a conv epilogue (a channel window of a padded
+// activation buffer).
+struct PhDst {
+  bf16* base;
+  int Hp, Wp, Cs;   // padded height/width, channel stride of the buffer
+  int org;          // element offset of interior pixel (0,0) channel window start
+};
+
+struct PhConvParams {
+  const bf16* in;    // padded NHWC input buffer
+  const bf16* wt;    // [CoutPad][Kpad] bf16, k = (kh*KW+kw)*cin_read + c
+  const float* bias; // [CoutPad]
+  const float* slope;// [CoutPad] PReLU slopes (act == 2)
+  int B, H, W, M;    // output pixels M = B*H*W
+  int in_Hp, in_Wp, in_Cs;
+  int in_org;        // element offset of tap (0,0) of output pixel (0,0,0)
+  int cin_read, KW, K, Kpad, nk;
+  unsigned magic_cin, magic_kw;
+  int cout, act;     // act: 0 none, 1 ReLU, 2 PReLU
+  int n_dst;
+  PhDst dst[PH_MAX_DST];
+  float* f32_out;    // optional NCHW fp32 [B][f32_C][H][W] written at f32_coff
+  int f32_C, f32_coff;
+  int n_mtiles, n_ntiles;
+};
+
+__host__ __device__ static inline unsigned ph_magic(unsigned d) {
+  // ceil(2^32 / d): __umulhi(n, magic) == n / d whenever n * d < 2^32
+  return (unsigned)((0x100000000ull + d - 1) / d);
+}
+// n / d for n*d < 2^32 (true for every operand pair used here; checked on host)
+__device__ static inline unsigned ph_div(unsigned n, unsigned magic, unsigned d) {
+  return d == 1 ? n : __umulhi(n, magic);
+}
+
+#define PH_CHECK(expr)                                                        \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      ph_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,               \
+                   hipGetErrorString(_e));                                    \
+      return -1;                                                              \
+    }                                                                         \
+  } while (0)
+
+void ph_set_error(const char* fmt, ...);

@@ -1,0 +1,35 @@
+// Internal declarations for the V2 decode launcher (csrc/decode_v2.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct PhV2Dev {
+  int n_parts, n_heat, n_pairs, max_peaks;
+  int ear_pair0, ear_pair1, min_subset_cnt;
+  float nms_threshold, inter_threshold, inter_min_above, min_subset_score;
+  float close_score;   // float(double(nms_threshold) + 1e-6)
+  double close_thr;    // sqrt(double(Wt*Ht)) / 150
+  int pairs[128];
+  int mapidx[128];
+};
+
+struct PhV2Sizes {
+  size_t peaks, pair_scores, conn_idx, conn_score, n_conn, n_people, keypoints, scores, subsets;
+};
+
+struct PhV2Buffers {
+  float* peaks;
+  float* pair_scores;
+  int* conn_idx;
+  float* conn_score;
+  int* n_conn;
+  int* n_people;
+  float* keypoints;
+  float* scores;
+  int* subsets;
+  int* overflow;
+};
+
+int ph_v2_workspace_sizes(const PhV2Dev& m, int B, int max_people, PhV2Sizes* s);
+int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int Wt, const PhV2Dev& m, int B,
+                        float scale, int max_people, const PhV2Buffers& w, hipStream_t stream, hipEvent_t* ev);

@@ -1,0 +1,175 @@
+"""Thin host wrapper over one ``ph_ctx`` (one device, one HIP stream).
+
+All arithmetic happens in libposehip.so; this class only marshals NumPy / torch
+buffers across the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .tables import V2_MODELS
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    def __init__(self, device=0, stream=None):
+        self._lib = _ffi.lib()
+        self._ctx = C.c_void_p()
+        _ffi.check(self._lib.ph_create(C.byref(self._ctx), int(device),
+                                       C.c_void_p(stream) if stream else None), "ph_create")
+        self.device = device
+        self.plan = None
+        self.batch = 0
+        self._v2_structs = {}
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.ph_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- network ---------------------------------------------------------
+    def build(self, plan, batch):
+        bufs, ops = plan.to_ctypes()
+        _ffi.check(self._lib.ph_net_build(self._ctx, int(batch), bufs, len(plan.bufs), ops, len(plan.ops),
+                                          plan.out_channels, plan.out_h, plan.out_w), "ph_net_build")
+        self.plan = plan
+        self.batch = batch
+
+    def preprocess(self, frames, mode=_ffi.PH_PRE_CV2):
+        """frames: u8 [B,H0,W0,3] BGR -- NumPy (host) or a torch CUDA tensor."""
+        if isinstance(frames, np.ndarray):
+            f = np.ascontiguousarray(frames, dtype=np.uint8)
+            if f.ndim != 4 or f.shape[3] != 3:
+                raise ValueError(f"frames must be u8 [B,H,W,3], got {f.shape}")
+            B, H0, W0, _ = f.shape
+            _ffi.check(self._lib.ph_preprocess(self._ctx, _ptr(f), 0, B, H0, W0, mode), "ph_preprocess")
+            self._lib.ph_sync(self._ctx)  # host buffer may go away after return
+        else:  # torch tensor on the device
+            if frames.dim() != 4 or frames.shape[3] != 3 or not frames.is_contiguous() or not frames.is_cuda:
+                raise ValueError("device frames must be a contiguous CUDA u8 [B,H,W,3] tensor")
+            B, H0, W0, _ = frames.shape
+            _ffi.check(self._lib.ph_preprocess(self._ctx, C.c_void_p(frames.data_ptr()), 1, B, H0, W0, mode),
+                       "ph_preprocess")
+        return B
+
+    def forward(self, B):
+        _ffi.check(self._lib.ph_forward(self._ctx, int(B)), "ph_forward")
+
+    def forward_timed(self, B, wait=True):
+        """Forward with per-op HIP events; wait=False only records them."""
+        if not wait:
+            _ffi.check(self._lib.ph_forward_timed(self._ctx, int(B), None), "ph_forward_timed")
+            return None
+        ms = (C.c_float * len(self.plan.ops))()
+        _ffi.check(self._lib.ph_forward_timed(self._ctx, int(B), ms), "ph_forward_timed")
+        return np.array(ms[:], dtype=np.float64)
+
+    def forward_times(self):
+        """Per-op device ms of the last forward_timed (synchronises the stream)."""
+        ms = (C.c_float * len(self.plan.ops))()
+        _ffi.check(self._lib.ph_forward_times(self._ctx, ms), "ph_forward_times")
+        return np.array(ms[:], dtype=np.float64)
+
+    def op_flops(self):
+        return np.array([max(0.0, self._lib.ph_op_flops(self._ctx, i)) for i in range(len(self.plan.ops))])
+
+    def net_out(self, B):
+        p = self.plan
+        out = np.empty((B, p.out_channels, p.out_h, p.out_w), np.float32)
+        _ffi.check(self._lib.ph_get_net_out(self._ctx, int(B), _ptr(out)), "ph_get_net_out")
+        return out
+
+    def set_net_out(self, arr):
+        """Inject a net output, f32 [B,C,Hs,Ws] (NumPy or torch CUDA tensor)."""
+        if isinstance(arr, np.ndarray):
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            B, Cc, Hs, Ws = a.shape
+            _ffi.check(self._lib.ph_set_net_out(self._ctx, _ptr(a), 0, B, Cc, Hs, Ws), "ph_set_net_out")
+        else:
+            B, Cc, Hs, Ws = arr.shape
+            _ffi.check(self._lib.ph_set_net_out(self._ctx, C.c_void_p(arr.data_ptr()), 1, B, Cc, Hs, Ws),
+                       "ph_set_net_out")
+        self._injected = (B, Cc, Hs, Ws)
+
+    def get_buffer(self, buf):
+        """Debug: bf16 activation buffer as float32 [B,Hp,Wp,C]."""
+        d = self.plan.bufs[buf]
+        shape = (self.batch, d["height"] + 2 * d["pad"], d["width"] + 2 * d["pad"], d["channels"])
+        raw = np.empty(shape, np.uint16)
+        _ffi.check(self._lib.ph_get_buffer(self._ctx, buf, _ptr(raw), raw.size), "ph_get_buffer")
+        return (raw.astype(np.uint32) << 16).view(np.float32)
+
+    def sync(self):
+        _ffi.check(self._lib.ph_sync(self._ctx), "ph_sync")
+
+    # ---- decode ----------------------------------------------------------
+    def _v2(self, model):
+        if isinstance(model, str):
+            model = V2_MODELS[model]
+        key = id(model)
+        if key not in self._v2_structs:
+            self._v2_structs[key] = (_ffi.v2_model_struct(model), model)
+        return self._v2_structs[key]
+
+    def decode_v2(self, model, B, Ht, Wt, scale=1.0, max_people=128, want_peaks=False, want_subsets=False):
+        """-> list of (keypoints f32 [M,J,3], scores f32 [M]) per frame (+extras)."""
+        ms, model = self._v2(model)
+        J = model.n_parts
+        n = np.zeros((B,), np.int32)
+        kp = np.zeros((B, max_people, J, 3), np.float32)
+        sc = np.zeros((B, max_people), np.float32)
+        peaks = np.zeros((B, J, model.max_peaks + 1, 3), np.float32) if want_peaks else None
+        subs = np.zeros((B, max_people, J + 1), np.int32) if want_subsets else None
+        _ffi.check(self._lib.ph_decode_v2(self._ctx, C.byref(ms), int(B), int(Ht), int(Wt), float(scale),
+                                          int(max_people), _ptr(n), _ptr(kp), _ptr(sc),
+                                          _ptr(peaks) if want_peaks else None,
+                                          _ptr(subs) if want_subsets else None), "ph_decode_v2")
+        res = []
+        for b in range(B):
+            m = min(int(n[b]), max_people)
+            res.append((kp[b, :m].copy(), sc[b, :m].copy()))
+        extras = dict(n_people=n, peaks=peaks, subsets=subs)
+        return res, extras
+
+    def decode_v2_dev(self, model, B, Ht, Wt, scale=1.0, max_people=128):
+        """Decode and leave results on the device; returns raw device addresses
+        (n_people i32[B], keypoints f32[B,max_people,J,3], scores f32[B,max_people])."""
+        ms, model = self._v2(model)
+        pn, pk, ps = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _ffi.check(self._lib.ph_decode_v2_dev(self._ctx, C.byref(ms), int(B), int(Ht), int(Wt), float(scale),
+                                              int(max_people), C.byref(pn), C.byref(pk), C.byref(ps)),
+                   "ph_decode_v2_dev")
+        return pn.value, pk.value, ps.value
+
+    def decode_v2_results(self, n_people, keypoints, scores):
+        """Async copy of the last decode_v2_dev results into torch tensors
+        (pinned host or CUDA); the caller synchronises the stream."""
+        on_dev = int(keypoints.is_cuda)
+        _ffi.check(self._lib.ph_decode_v2_results(self._ctx, C.c_void_p(n_people.data_ptr()),
+                                                  C.c_void_p(keypoints.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                                  on_dev), "ph_decode_v2_results")
+
+    def decode_v2_connections(self, model, B):
+        """Test/debug: per-limb connection lists of the last decode."""
+        _, model = self._v2(model)
+        n = np.zeros((B, model.n_pairs), np.int32)
+        idx = np.zeros((B, model.n_pairs, model.max_peaks, 2), np.int32)
+        sc = np.zeros((B, model.n_pairs, model.max_peaks), np.float32)
+        _ffi.check(self._lib.ph_decode_v2_connections(self._ctx, _ptr(n), _ptr(idx), _ptr(sc)),
+                   "ph_decode_v2_connections")
+        return n, idx, sc
+
+    def decode_v2_times(self):
+        ms = (C.c_float * 3)()
+        _ffi.check(self._lib.ph_decode_v2_times(self._ctx, ms), "ph_decode_v2_times")
+        return list(ms)

@@ -1,0 +1,108 @@
+"""GPU parity: MFMA implicit-GEMM conv / pool / concat plan vs the torch fp32
+oracle (oracle/net_ref.py), through the C ABI."""
+import numpy as np
+import pytest
+
+from posehip import _ffi, caffe_io, graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_net(h, w, spec):
+    """spec: list of ('conv', name, bottom, cout, k, act) | ('pool', name, bottom) | ('concat', name, [bottoms])."""
+    s = f'input: "image"\ninput_dim: 1\ninput_dim: 3\ninput_dim: {h}\ninput_dim: {w}\n'
+    for it in spec:
+        if it[0] == "conv":
+            _, name, bottom, cout, k, act = it
+            s += caffe_io._conv(name, bottom, cout, k)
+            if act:
+                s += caffe_io._act(act, "act_" + name, name)
+        elif it[0] == "pool":
+            s += caffe_io._pool(it[1], it[2])
+        else:
+            s += caffe_io._concat(it[1], it[2])
+    return caffe_io.parse_prototxt(s)
+
+
+def _run(engine, net, weights, x_u8, batch):
+    from oracle import net_ref
+    plan = graph.build_plan(net, weights)
+    engine.build(plan, batch)
+    B = engine.preprocess(x_u8, _ffi.PH_PRE_CV2)
+    engine.forward(B)
+    got = engine.net_out(B)
+    x = x_u8.astype(np.float32).transpose(0, 3, 1, 2) * np.float32(1.0 / 255.0)
+    ref16 = net_ref.forward(net, weights, x, bf16_sim=True)
+    ref32 = net_ref.forward(net, weights, x, bf16_sim=False)
+    return got, ref16, ref32
+
+
+CASES = {
+    # exercises: Cin=3 first layer, 3x3, ReLU, pool, PReLU, 1x1, concat-by-offset with
+    # unaligned member widths (26/52 -> 8-aligned windows), 7x7, odd spatial sizes, M tails
+    "vgg_like": (24, 40, [("conv", "c1", "image", 64, 3, "ReLU"), ("conv", "c2", "c1", 64, 3, "ReLU"),
+                           ("pool", "p1", "c2"), ("conv", "c3", "p1", 128, 3, "PReLU"),
+                           ("conv", "out", "c3", 26, 1, None)]),
+    "dense_concat": (16, 24, [("conv", "f", "image", 128, 3, "PReLU"),
+                               ("conv", "a0", "f", 96, 3, "PReLU"), ("conv", "a1", "a0", 96, 3, "PReLU"),
+                               ("conv", "a2", "a1", 96, 3, "PReLU"), ("concat", "cat1", ["a0", "a1", "a2"]),
+                               ("conv", "m6", "cat1", 256, 1, "PReLU"), ("conv", "l2", "m6", 52, 1, None),
+                               ("concat", "cat2", ["f", "l2"]),
+                               ("conv", "b0", "cat2", 128, 3, "PReLU"), ("conv", "l1", "b0", 26, 1, None),
+                               ("concat", "cat3", ["f", "l1", "l2"]),
+                               ("conv", "c0", "cat3", 96, 3, "ReLU"), ("conv", "l1b", "c0", 26, 1, None),
+                               ("concat", "net_output", ["l1b", "l2"])]),
+    "k7": (14, 18, [("conv", "f", "image", 64, 3, "ReLU"), ("conv", "g", "f", 128, 7, "ReLU"),
+                     ("conv", "out", "g", 19, 1, None)]),
+    "odd_pool": (13, 19, [("conv", "c1", "image", 64, 3, "ReLU"), ("pool", "p", "c1"),
+                           ("conv", "out", "p", 38, 3, None)]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("batch", [1, 3])
+def test_small_nets_match_oracle(engine, case, batch):
+    h, w, spec = CASES[case]
+    net = _tiny_net(h, w, spec)
+    weights = graph.random_weights(net, seed=7, out_gain=1.0)
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, (batch, h, w, 3), dtype=np.uint8)
+    got, ref16, ref32 = _run(engine, net, weights, x, batch)
+    assert got.shape == ref32.shape
+    scale = np.abs(ref32).max() + 1e-6
+    # vs bf16-storage emulation: only fp32 accumulation-order noise (+ rare 1-ulp bf16 flips)
+    assert np.abs(got - ref16).max() / scale < 1e-2, np.abs(got - ref16).max() / scale
+    # vs pure fp32: bf16 storage of weights/activations, a few layers deep
+    assert np.abs(got - ref32).max() / scale < 3e-2, np.abs(got - ref32).max() / scale
+    assert np.isfinite(got).all()
+
+
+def test_forward_is_deterministic_and_batch_invariant(engine):
+    h, w, spec = CASES["dense_concat"]
+    net = _tiny_net(h, w, spec)
+    weights = graph.random_weights(net, seed=1, out_gain=1.0)
+    plan = graph.build_plan(net, weights)
+    engine.build(plan, 4)
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (4, h, w, 3), dtype=np.uint8)
+    engine.preprocess(x, _ffi.PH_PRE_CV2)
+    engine.forward(4)
+    a = engine.net_out(4)
+    engine.preprocess(x[2:3], _ffi.PH_PRE_CV2)
+    engine.forward(1)
+    b = engine.net_out(1)
+    assert np.array_equal(a[2], b[0])          # frames are independent units
+    engine.preprocess(x, _ffi.PH_PRE_CV2)
+    engine.forward(4)
+    assert np.array_equal(a, engine.net_out(4))
+
+
+def test_bad_plans_fail_loudly(engine):
+    net = _tiny_net(8, 8, [("conv", "out", "image", 8, 3, None)])
+    weights = graph.random_weights(net, seed=0)
+    plan = graph.build_plan(net, weights)
+    plan.ops[0]["in_coff"] = 4                  # misaligned channel window
+    with pytest.raises(_ffi.PosehipError):
+        engine.build(plan, 1)
+    with pytest.raises(_ffi.PosehipError):
+        engine.forward(1)                        # nothing built after the failure
