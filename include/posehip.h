@@ -110,6 +110,13 @@ int ph_get_net_out(ph_ctx* ctx, int B, float* host_out);
 float* ph_net_out_dev(ph_ctx* ctx);
 /* inject a net output (predict_from_hm, native/python/skeleton.py:469-481) */
 int ph_set_net_out(ph_ctx* ctx, const float* src, int on_device, int B, int C, int Hs, int Ws);
+/* bicubic-upsampled maps of one frame, channels [c0, c0+nc), to host f32
+ * [nc][Ht][Wt]: datum.poseHeatMaps export (native/python/skeleton.py:64-76). */
+int ph_upsample_maps(ph_ctx* ctx, int frame, int c0, int nc, int Ht, int Wt, float* host_out);
+/* per-map global max and first raster location of it for all B*C maps of the
+ * net output: cv2.minMaxLoc per heat map in postprocess_single
+ * (opencv/skeleton.py:88-99).  vals f32 [B*C], locs i32 [B*C] (= y*Ws + x). */
+int ph_argmax_maps(ph_ctx* ctx, int B, float* vals_host, int32_t* locs_host);
 /* debug/test: copy an activation buffer (bf16 bits) to host */
 int ph_get_buffer(ph_ctx* ctx, int buf, uint16_t* host_out, int64_t n_elems);
 

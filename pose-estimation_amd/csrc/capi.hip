@@ -491,6 +491,46 @@ int ph_get_buffer(ph_ctx* c, int buf, uint16_t* host_out, int64_t n_elems) {
   return 0;
 }
 
+int ph_upsample_maps(ph_ctx* c, int frame, int c0, int nc, int Ht, int Wt, float* host_out) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!c->net_out || frame < 0 || c0 < 0 || nc < 1 || c0 + nc > c->cur_c || Ht < 1 || Wt < 1 ||
+      (size_t)(frame + 1) * c->cur_c * c->cur_h * c->cur_w > c->net_out_elems) {
+    ph_set_error("ph_upsample_maps: bad frame/channel window");
+    return -1;
+  }
+  float* tmp = nullptr;
+  const size_t n = (size_t)nc * Ht * Wt;
+  PH_CHECK(hipMalloc(&tmp, n * sizeof(float)));
+  const float* planes = c->net_out + ((size_t)frame * c->cur_c + c0) * c->cur_h * c->cur_w;
+  int rc = ph_launch_upsample_maps(planes, c->cur_h, c->cur_w, Ht, Wt, nc, tmp, c->stream);
+  if (!rc && hipMemcpyAsync(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
+  (void)hipFree(tmp);
+  if (rc) ph_set_error("ph_upsample_maps: launch or copy failed");
+  return rc;
+}
+
+int ph_argmax_maps(ph_ctx* c, int B, float* vals_host, int32_t* locs_host) {
+  PH_CHECK(hipSetDevice(c->device));
+  const int n_maps = B * c->cur_c, n = c->cur_h * c->cur_w;
+  if (!c->net_out || B < 1 || (size_t)n_maps * n > c->net_out_elems) {
+    ph_set_error("ph_argmax_maps: no net output for batch %d", B);
+    return -1;
+  }
+  float* dv = nullptr;
+  int* dl = nullptr;
+  PH_CHECK(hipMalloc(&dv, n_maps * sizeof(float)));
+  PH_CHECK(hipMalloc(&dl, n_maps * sizeof(int)));
+  int rc = ph_launch_argmax_maps(c->net_out, n_maps, n, dv, dl, c->stream);
+  if (!rc && hipMemcpyAsync(vals_host, dv, n_maps * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -1;
+  if (!rc && hipMemcpyAsync(locs_host, dl, n_maps * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
+  (void)hipFree(dv);
+  (void)hipFree(dl);
+  if (rc) ph_set_error("ph_argmax_maps: launch or copy failed");
+  return rc;
+}
+
 // ---- V2 decode ---------------------------------------------------------------
 static int v2_prepare(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, int max_people, PhV2Dev* dev) {
   PH_CHECK(hipSetDevice(c->device));

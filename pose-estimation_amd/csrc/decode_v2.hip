@@ -461,6 +461,74 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// optional: materialise upsampled maps (datum.poseHeatMaps export only -- the
+// decode itself never needs them).  grid-stride over [nc][Ht][Wt] of one frame.
+// ---------------------------------------------------------------------------
+__global__ void upsample_maps_kernel(const float* __restrict__ planes, int hs, int ws, int Ht, int Wt, int nc,
+                                     float* __restrict__ out) {
+  const size_t total = (size_t)nc * Ht * Wt;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % Wt;
+    const size_t t = i / Wt;
+    const int y = t % Ht;
+    const int c = t / Ht;
+    out[i] = bicubic_at(planes + (size_t)c * hs * ws, hs, ws, Ht, Wt, x, y);
+  }
+}
+
+int ph_launch_upsample_maps(const float* planes, int hs, int ws, int Ht, int Wt, int nc, float* out,
+                            hipStream_t stream) {
+  const size_t total = (size_t)nc * Ht * Wt;
+  int blocks = (int)((total + 255) / 256);
+  blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
+  hipLaunchKernelGGL(upsample_maps_kernel, dim3(blocks), dim3(256), 0, stream, planes, hs, ws, Ht, Wt, nc, out);
+  PH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// per-map global maximum and its first (raster) location: the reference's
+// single-pose decode, cv2.minMaxLoc per heat map (openpose/opencv/skeleton.py:95)
+__global__ __launch_bounds__(256) void argmax_maps_kernel(const float* __restrict__ maps, int n, float* __restrict__ vals,
+                                                          int* __restrict__ locs) {
+  __shared__ float s_v[256];
+  __shared__ int s_i[256];
+  const float* m = maps + (size_t)blockIdx.x * n;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = m[i];
+    if (v > bv) {  // strided scan: the lowest index among equal maxima wins below
+      bv = v;
+      bi = i;
+    }
+  }
+  s_v[threadIdx.x] = bv;
+  s_i[threadIdx.x] = bi;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      const float ov = s_v[threadIdx.x + st];
+      const int oi = s_i[threadIdx.x + st];
+      if (ov > s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x])) {
+        s_v[threadIdx.x] = ov;
+        s_i[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    vals[blockIdx.x] = s_v[0];
+    locs[blockIdx.x] = s_i[0] == 0x7fffffff ? 0 : s_i[0];
+  }
+}
+
+int ph_launch_argmax_maps(const float* maps, int n_maps, int n, float* vals, int* locs, hipStream_t stream) {
+  hipLaunchKernelGGL(argmax_maps_kernel, dim3(n_maps), dim3(256), 0, stream, maps, n, vals, locs);
+  PH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // host launcher
 // ---------------------------------------------------------------------------
 int ph_v2_workspace_sizes(const PhV2Dev& m, int B, int max_people, PhV2Sizes* s) {

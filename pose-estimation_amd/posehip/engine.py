@@ -101,6 +101,19 @@ class Engine:
                        "ph_set_net_out")
         self._injected = (B, Cc, Hs, Ws)
 
+    def upsample_maps(self, frame, c0, nc, Ht, Wt):
+        out = np.empty((nc, Ht, Wt), np.float32)
+        _ffi.check(self._lib.ph_upsample_maps(self._ctx, int(frame), int(c0), int(nc), int(Ht), int(Wt), _ptr(out)),
+                   "ph_upsample_maps")
+        return out
+
+    def argmax_maps(self, B, C_, Ws):
+        """-> (max value f32 [B,C], x i32 [B,C], y i32 [B,C]) of the net output maps."""
+        vals = np.empty((B * C_,), np.float32)
+        locs = np.empty((B * C_,), np.int32)
+        _ffi.check(self._lib.ph_argmax_maps(self._ctx, int(B), _ptr(vals), _ptr(locs)), "ph_argmax_maps")
+        return vals.reshape(B, C_), (locs % Ws).reshape(B, C_), (locs // Ws).reshape(B, C_)
+
     def get_buffer(self, buf):
         """Debug: bf16 activation buffer as float32 [B,Hp,Wp,C]."""
         d = self.plan.bufs[buf]
