@@ -79,6 +79,15 @@ typedef struct {
   int mapidx[64 * 2]; /* PAF channel pair per limb, relative to n_heat */
 } ph_v2_model;
 
+/* In-tree decode constants ("V1"; openpose/opencv/common.py MAPIDX :26-28 and
+ * the body_parts / pose_pairs of get_body_parts_and_pose_pairs :31-102). */
+typedef struct {
+  int n_parts;             /* len(body_parts) - 1: heat maps decoded (background excluded) */
+  int n_limbs;             /* len(MAPIDX) */
+  int pair_parts[32 * 2];  /* body_parts[pose_pairs[k][0..1]] */
+  int mapidx[32 * 2];      /* absolute PAF channels MAPIDX[k][0..1] */
+} ph_v1_model;
+
 /* ---- lifecycle ---------------------------------------------------------- */
 /* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to
  * create a private one.  Stands in for cv2.dnn.readNetFromCaffe's Net object /
@@ -148,6 +157,25 @@ int ph_decode_v2_connections(ph_ctx* ctx, int32_t* n_conn, int32_t* conn_idx, fl
 /* device time (ms) of the decode kernels of the last ph_decode_v2* call:
  * [0] upsample+NMS, [1] PAF scoring+matching, [2] assembly */
 int ph_decode_v2_times(ph_ctx* ctx, float* ms3);
+
+/* ---- V1 decode (replaces PyOpenPoseOpenCV.postprocess_multi and its helpers
+ *      getKeypoints / getValidPairs / getPersonwiseKeypoints,
+ *      opencv/skeleton.py:102-154, opencv/utils.py:9-173) ----------------------
+ * Decodes the ctx's net output for B frames at ORIGINAL-IMAGE resolution
+ * W0 x H0 (bilinear-resized maps never materialised).  Host outputs:
+ *   n_kps     int32 [B][n_parts]                 keypoints per part (findContours order)
+ *   kps       f32   [B][n_parts][kp_cap][3]      (x, y, score); ids run over parts in order
+ *   n_pairs   int32 [B][n_limbs]                 rows per limb, -1 = "invalid pair"
+ *   pairs     f64   [B][n_limbs][kp_cap][3]      (idA, idB, mean PAF score)
+ *   n_persons int32 [B]
+ *   persons   f64   [B][person_cap][n_parts+1]   keypoint ids (-1 = missing) + total score
+ * Returns -2 when a capacity (kp_cap blobs per part, person_cap people, 8192
+ * mask runs per part) is exceeded. */
+int ph_decode_v1(ph_ctx* ctx, const ph_v1_model* model, int B, int W0, int H0, float conf_thres, int kp_cap,
+                 int person_cap, int32_t* n_kps, float* kps, int32_t* n_pairs, double* pairs, int32_t* n_persons,
+                 double* persons);
+/* device time (ms) of the last ph_decode_v1: [0] resize+blur+runs, [1] blobs, [2] pairs+assembly */
+int ph_decode_v1_times(ph_ctx* ctx, float* ms3);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 
 #include "../../include/posehip.h"
 #include "common.h"
+#include "decode_v1.h"
 #include "decode_v2.h"
 
 int ph_launch_conv(const PhConvParams& p, int nrep, hipStream_t stream);
@@ -66,7 +67,11 @@ struct ph_ctx {
   PhV2Buffers v2 = {};
   PhV2Sizes v2sz = {};
   size_t v2_key = 0;
+  V1Buffers v1 = {};
+  V1Sizes v1sz = {};
+  size_t v1_key = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev1[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> op_ev;
 };
 
@@ -115,6 +120,7 @@ int ph_create(ph_ctx** out, int device, void* stream) {
     c->own_stream = true;
   }
   for (int i = 0; i < 4; i++) PH_CHECK(hipEventCreate(&c->ev[i]));
+  for (int i = 0; i < 4; i++) PH_CHECK(hipEventCreate(&c->ev1[i]));
   *out = c;
   return 0;
 }
@@ -142,12 +148,24 @@ static void free_v2(ph_ctx* c) {
   c->v2_key = 0;
 }
 
+static void free_v1(ph_ctx* c) {
+  void* ptrs[] = {c->v1.n_runs, c->v1.runs,    c->v1.ws_best, c->v1.ws_first,  c->v1.kps,     c->v1.n_kps,
+                  c->v1.pairs,  c->v1.n_pairs, c->v1.persons, c->v1.n_persons, c->v1.overflow};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  c->v1 = V1Buffers{};
+  c->v1_key = 0;
+}
+
 void ph_destroy(ph_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_net(c);
   free_v2(c);
+  free_v1(c);
+  for (int i = 0; i < 4; i++)
+    if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
   if (c->net_out) (void)hipFree(c->net_out);
   if (c->frames) (void)hipFree(c->frames);
   for (int i = 0; i < 4; i++)
@@ -646,6 +664,76 @@ int ph_decode_v2_connections(ph_ctx* c, int32_t* n_conn, int32_t* conn_idx, floa
   if (conn_idx) PH_CHECK(hipMemcpyAsync(conn_idx, c->v2.conn_idx, c->v2sz.conn_idx, hipMemcpyDeviceToHost, s));
   if (conn_score) PH_CHECK(hipMemcpyAsync(conn_score, c->v2.conn_score, c->v2sz.conn_score, hipMemcpyDeviceToHost, s));
   PH_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---- V1 decode ---------------------------------------------------------------
+int ph_decode_v1(ph_ctx* c, const ph_v1_model* m, int B, int W0, int H0, float conf_thres, int kp_cap,
+                 int person_cap, int32_t* n_kps, float* kps, int32_t* n_pairs, double* pairs, int32_t* n_persons,
+                 double* persons) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!m || B < 1 || kp_cap < 1 || person_cap < 1 || !c->net_out ||
+      (size_t)B * c->cur_c * c->cur_h * c->cur_w > c->net_out_elems) {
+    ph_set_error("ph_decode_v1: bad args or no net output for batch %d", B);
+    return -1;
+  }
+  if (m->n_parts < 1 || m->n_parts > V1_MAX_PARTS || m->n_limbs < 1 || m->n_limbs > V1_MAX_LIMBS) {
+    ph_set_error("ph_decode_v1: bad model constants");
+    return -1;
+  }
+  V1Model dev;
+  memset(&dev, 0, sizeof(dev));
+  dev.n_parts = m->n_parts;
+  dev.n_limbs = m->n_limbs;
+  memcpy(dev.pair_parts, m->pair_parts, sizeof(int) * 2 * m->n_limbs);
+  memcpy(dev.mapidx, m->mapidx, sizeof(int) * 2 * m->n_limbs);
+  V1Caps caps;
+  caps.run_cap = 8192;
+  caps.kp_cap = kp_cap;
+  caps.person_cap = person_cap;
+  const size_t key = ((size_t)B << 44) ^ ((size_t)kp_cap << 28) ^ ((size_t)person_cap << 12) ^
+                     ((size_t)m->n_parts << 6) ^ (size_t)m->n_limbs;
+  if (key != c->v1_key) {
+    PH_CHECK(hipStreamSynchronize(c->stream));
+    free_v1(c);
+    ph_v1_sizes(dev, B, W0, H0, caps, &c->v1sz);
+    PH_CHECK(hipMalloc(&c->v1.n_runs, c->v1sz.n_runs));
+    PH_CHECK(hipMalloc(&c->v1.runs, c->v1sz.runs));
+    PH_CHECK(hipMalloc(&c->v1.ws_best, c->v1sz.ws_best));
+    PH_CHECK(hipMalloc(&c->v1.ws_first, c->v1sz.ws_first));
+    PH_CHECK(hipMalloc(&c->v1.kps, c->v1sz.kps));
+    PH_CHECK(hipMalloc(&c->v1.n_kps, c->v1sz.n_kps));
+    PH_CHECK(hipMalloc(&c->v1.pairs, c->v1sz.pairs));
+    PH_CHECK(hipMalloc(&c->v1.n_pairs, c->v1sz.n_pairs));
+    PH_CHECK(hipMalloc(&c->v1.persons, c->v1sz.persons));
+    PH_CHECK(hipMalloc(&c->v1.n_persons, c->v1sz.n_persons));
+    PH_CHECK(hipMalloc(&c->v1.overflow, sizeof(int)));
+    c->v1_key = key;
+  }
+  if (ph_launch_decode_v1(c->net_out, c->cur_c, c->cur_h, c->cur_w, W0, H0, conf_thres, dev, B, caps, c->v1,
+                          c->stream, c->ev1))
+    return -1;
+  hipStream_t s = c->stream;
+  if (n_kps) PH_CHECK(hipMemcpyAsync(n_kps, c->v1.n_kps, c->v1sz.n_kps, hipMemcpyDeviceToHost, s));
+  if (kps) PH_CHECK(hipMemcpyAsync(kps, c->v1.kps, c->v1sz.kps, hipMemcpyDeviceToHost, s));
+  if (n_pairs) PH_CHECK(hipMemcpyAsync(n_pairs, c->v1.n_pairs, c->v1sz.n_pairs, hipMemcpyDeviceToHost, s));
+  if (pairs) PH_CHECK(hipMemcpyAsync(pairs, c->v1.pairs, c->v1sz.pairs, hipMemcpyDeviceToHost, s));
+  if (n_persons) PH_CHECK(hipMemcpyAsync(n_persons, c->v1.n_persons, c->v1sz.n_persons, hipMemcpyDeviceToHost, s));
+  if (persons) PH_CHECK(hipMemcpyAsync(persons, c->v1.persons, c->v1sz.persons, hipMemcpyDeviceToHost, s));
+  int overflow = 0;
+  PH_CHECK(hipMemcpyAsync(&overflow, c->v1.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+  PH_CHECK(hipStreamSynchronize(s));
+  if (overflow) {
+    ph_set_error("ph_decode_v1: capacity exceeded (more than %d mask runs or %d blobs per part, or %d people)",
+                 caps.run_cap, kp_cap, person_cap);
+    return -2;
+  }
+  return 0;
+}
+
+int ph_decode_v1_times(ph_ctx* c, float* ms3) {
+  PH_CHECK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 3; i++) PH_CHECK(hipEventElapsedTime(&ms3[i], c->ev1[i], c->ev1[i + 1]));
   return 0;
 }
 

@@ -1,0 +1,542 @@
+// "V1" decode for gfx950: the reference's in-tree multi-person decode
+//   PyOpenPoseOpenCV.postprocess_multi   openpose/opencv/skeleton.py:102-154
+//   getKeypoints                         openpose/opencv/utils.py:9-23
+//   getValidPairs                        openpose/opencv/utils.py:27-131
+//   getPersonwiseKeypoints               openpose/opencv/utils.py:136-173
+// run at ORIGINAL-IMAGE resolution (up to 1920x1080) without ever writing the
+// bilinearly resized maps (415 MB/frame at 1080p if materialised):
+//   K-A  per 16x256 tile: bilinear resize -> 3x3 Gaussian -> threshold -> row
+//        runs of the mask with their first-raster maxima (tiles whose source
+//        cells are all below threshold are skipped);
+//   K-B  per (frame, part): runs bucketed by row in LDS, lock-free union-find
+//        over touching runs (8-connectivity) = the blobs cv2.findContours
+//        traces, per-blob arg-max, findContours list order;
+//   K-C  per (frame, limb): 10-sample nearest-pixel PAF line integral in fp64,
+//        per-A arg-max, ordered compaction;
+//   K-D  per frame: person assembly in LDS.
+// Bit-exact against oracle/decode_v1.py (same IEEE operations, same order;
+// built with -ffp-contract=off).  Stated deviations from literal cv2 blob
+// semantics are listed in that file's header.
+#include "common.h"
+#include "decode_v1.h"
+
+#define V1_TILE_H 16
+#define V1_TILE_W 256
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  if (p < 0) p = -p;
+  if (p >= n) p = 2 * (n - 1) - p;
+  return p;
+}
+
+// cv2.resize INTER_LINEAR coordinate (x axis: weight reset at the clamps)
+struct LinX {
+  int s0, s1;
+  float a0, a1;
+};
+__device__ __forceinline__ LinX lin_x(int d, int n_dst, int n_src) {
+  float fx = (float)(((double)d + 0.5) * ((double)n_src / (double)n_dst) - 0.5);
+  int sx = (int)floorf(fx);
+  fx = fx - (float)sx;
+  if (sx < 0) {
+    fx = 0.f;
+    sx = 0;
+  }
+  if (sx >= n_src - 1) {
+    fx = 0.f;
+    sx = n_src - 1;
+  }
+  LinX r;
+  r.s0 = sx;
+  r.s1 = sx + 1 > n_src - 1 ? n_src - 1 : sx + 1;
+  r.a0 = 1.f - fx;
+  r.a1 = fx;
+  return r;
+}
+// y axis: rows clipped, weights kept
+__device__ __forceinline__ LinX lin_y(int d, int n_dst, int n_src) {
+  float fy = (float)(((double)d + 0.5) * ((double)n_src / (double)n_dst) - 0.5);
+  const int sy = (int)floorf(fy);
+  fy = fy - (float)sy;
+  LinX r;
+  r.s0 = sy < 0 ? 0 : (sy > n_src - 1 ? n_src - 1 : sy);
+  r.s1 = sy + 1 < 0 ? 0 : (sy + 1 > n_src - 1 ? n_src - 1 : sy + 1);
+  r.a0 = 1.f - fy;
+  r.a1 = fy;
+  return r;
+}
+__device__ __forceinline__ float resize_at(const float* src, int hs, int ws, int W, int H, int x, int y) {
+  const LinX cx = lin_x(x, W, ws), cy = lin_y(y, H, hs);
+  const float r0 = src[cy.s0 * ws + cx.s0] * cx.a0 + src[cy.s0 * ws + cx.s1] * cx.a1;
+  const float r1 = src[cy.s1 * ws + cx.s0] * cx.a0 + src[cy.s1 * ws + cx.s1] * cx.a1;
+  return r0 * cy.a0 + r1 * cy.a1;
+}
+
+// ---------------------------------------------------------------------------
+// K-A: mask runs.  grid (tiles_x * tiles_y, n_parts, B), block 256
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void v1_runs_kernel(const float* __restrict__ net_out, int C, int hs, int ws, int W,
+                                                      int H, float thr, int n_parts, int run_cap,
+                                                      int* __restrict__ n_runs, V1Run* __restrict__ runs,
+                                                      int* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tiles_x = (W + V1_TILE_W - 1) / V1_TILE_W;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int part = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int x0 = tx * V1_TILE_W, y0 = ty * V1_TILE_H;
+  float* s_src = smem;                         // hs*ws
+  float* s_heat = s_src + hs * ws;             // (TILE_H+2) * (TILE_W+2)
+  float* s_t = s_heat + (V1_TILE_H + 2) * (V1_TILE_W + 2);  // (TILE_H+2) * TILE_W
+  float* s_sm = s_t + (V1_TILE_H + 2) * V1_TILE_W;          // TILE_H * TILE_W
+  __shared__ float s_max[4];
+
+  const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
+  // source cells that can reach this tile (1-px blur halo, both bilinear taps)
+  const int xa = x0 > 0 ? x0 - 1 : 0, xb = x0 + V1_TILE_W < W ? x0 + V1_TILE_W : W - 1;
+  const int ya = y0 > 0 ? y0 - 1 : 0, yb = y0 + V1_TILE_H < H ? y0 + V1_TILE_H : H - 1;
+  const int sxa = lin_x(xa, W, ws).s0, sxb = lin_x(xb, W, ws).s1;
+  const int sya = lin_y(ya, H, hs).s0, syb = lin_y(yb, H, hs).s1;
+  float lm = -INFINITY;
+  for (int i = tid; i < hs * ws; i += 256) {
+    const float v = plane[i];
+    s_src[i] = v;
+    const int yy = i / ws, xx = i - yy * ws;
+    if (yy >= sya && yy <= syb && xx >= sxa && xx <= sxb) lm = fmaxf(lm, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) lm = fmaxf(lm, __shfl_xor(lm, o));
+  if ((tid & 63) == 0) s_max[tid >> 6] = lm;
+  __syncthreads();
+  const float tile_max = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  // resize + blur are convex combinations up to a few ulps: nothing here can exceed thr
+  if (thr > 0.f && tile_max < thr * 0.999f) return;
+
+  // 1. bilinear-resized heat map, tile + 1-px halo, reflect-101 at the image border
+  constexpr int HW_ = V1_TILE_W + 2;
+  for (int i = tid; i < (V1_TILE_H + 2) * HW_; i += 256) {
+    const int r = i / HW_, c = i - r * HW_;
+    const int y = reflect101(y0 - 1 + r, H), x = reflect101(x0 - 1 + c, W);
+    s_heat[i] = (y0 - 1 + r <= H && x0 - 1 + c <= W) ? resize_at(s_src, hs, ws, W, H, x, y) : 0.f;
+  }
+  __syncthreads();
+  // 2. row pass  c*1/2 + (l + r)*1/4
+  for (int i = tid; i < (V1_TILE_H + 2) * V1_TILE_W; i += 256) {
+    const int r = i / V1_TILE_W, c = i - r * V1_TILE_W;
+    const float* h = s_heat + r * HW_ + c + 1;
+    s_t[i] = h[0] * 0.5f + (h[-1] + h[1]) * 0.25f;
+  }
+  __syncthreads();
+  // 3. column pass
+  for (int i = tid; i < V1_TILE_H * V1_TILE_W; i += 256) {
+    const int r = i / V1_TILE_W, c = i - r * V1_TILE_W;
+    const float* t = s_t + (r + 1) * V1_TILE_W + c;
+    const bool inside = y0 + r < H && x0 + c < W;
+    s_sm[i] = inside ? t[0] * 0.5f + (t[-V1_TILE_W] + t[V1_TILE_W]) * 0.25f : -INFINITY;
+  }
+  __syncthreads();
+  // 4. runs: the thread on a run's first pixel walks it
+  int* cnt = n_runs + (size_t)b * n_parts + part;
+  V1Run* out = runs + ((size_t)b * n_parts + part) * run_cap;
+  for (int i = tid; i < V1_TILE_H * V1_TILE_W; i += 256) {
+    const int r = i / V1_TILE_W, c = i - r * V1_TILE_W;
+    const float* row = s_sm + r * V1_TILE_W;
+    if (row[c] > thr && (c == 0 || !(row[c - 1] > thr))) {
+      float best = row[c];
+      int bx = c, e = c;
+      while (e + 1 < V1_TILE_W && row[e + 1] > thr) {
+        e++;
+        if (row[e] > best) {
+          best = row[e];
+          bx = e;
+        }
+      }
+      const int slot = atomicAdd(cnt, 1);
+      if (slot < run_cap) {
+        V1Run rn;
+        rn.y = y0 + r;
+        rn.xs = x0 + c;
+        rn.xe = x0 + e;
+        rn.bx = x0 + bx;
+        rn.best = best;
+        out[slot] = rn;
+      } else {
+        *overflow = 1;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K-B: blobs from runs.  grid (n_parts, B), block 256
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int uf_find(volatile int* parent, int i) {
+  int p = parent[i];
+  while (p != i) {
+    i = p;
+    p = parent[i];
+  }
+  return i;
+}
+__device__ void uf_union(int* parent, int a, int b) {
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) {
+      const int t = a;
+      a = b;
+      b = t;
+    }  // a > b: hook a under b
+    const int old = atomicCAS(&parent[a], a, b);
+    if (old == a) return;
+  }
+}
+
+__global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
+                                                       int W, int H, int n_parts, int run_cap, int kp_cap,
+                                                       const int* __restrict__ n_runs,
+                                                       const V1Run* __restrict__ runs,
+                                                       unsigned long long* __restrict__ ws_best,
+                                                       int* __restrict__ ws_first, float* __restrict__ kps,
+                                                       int* __restrict__ n_kps, int* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) int ismem[];
+  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  int n = n_runs[(size_t)b * n_parts + part];
+  n = n > run_cap ? run_cap : n;
+  float* out = kps + ((size_t)b * n_parts + part) * kp_cap * 3;
+  int* out_n = n_kps + (size_t)b * n_parts + part;
+  if (n == 0) {
+    if (tid == 0) *out_n = 0;
+    return;
+  }
+  const V1Run* R = runs + ((size_t)b * n_parts + part) * run_cap;
+  unsigned long long* best = ws_best + ((size_t)b * n_parts + part) * run_cap;
+  int* first = ws_first + ((size_t)b * n_parts + part) * run_cap;
+  int* parent = ismem;              // n
+  int* byrow = parent + run_cap;    // n: run indices grouped by row
+  int* rowoff = byrow + run_cap;    // H + 2
+  int* roots = rowoff + H + 2;      // kp_cap
+  __shared__ int s_nroot;
+  __shared__ int s_scan[256];
+
+  for (int i = tid; i < H + 2; i += 256) rowoff[i] = 0;
+  if (tid == 0) s_nroot = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    parent[i] = i;
+    atomicAdd(&rowoff[R[i].y + 1], 1);
+    best[i] = 0ull;
+    first[i] = 0x7fffffff;
+  }
+  __threadfence();  // the initial values must be in L2 before any atomic of step 3 lands there
+  __syncthreads();
+  // exclusive scan of the per-row counts (rowoff[y+1] = count of row y)
+  {
+    const int per = (H + 1 + 255) / 256;
+    const int lo = tid * per, hi = lo + per < H + 1 ? lo + per : H + 1;
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += rowoff[i + 1];
+    s_scan[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      for (int i = 0; i < 256; i++) {
+        const int t = s_scan[i];
+        s_scan[i] = acc;
+        acc += t;
+      }
+    }
+    __syncthreads();
+    int acc = s_scan[tid];
+    for (int i = lo; i < hi; i++) {
+      const int t = rowoff[i + 1];
+      rowoff[i + 1] = acc;   // start offset of row i
+      acc += t;
+    }
+  }
+  __syncthreads();
+  // rowoff[y+1] now = start of row y; scatter with a moving cursor, then restore
+  for (int i = tid; i < n; i += 256) byrow[atomicAdd(&rowoff[R[i].y + 1], 1)] = i;
+  __syncthreads();
+  // after the scatter rowoff[y+1] = end of row y = start of row y+1; row y spans [rowoff[y], rowoff[y+1])
+  // with rowoff[0] = 0 (row -1 is empty)
+  for (int i = tid; i < n; i += 256) {
+    const V1Run r = R[i];
+    // same row: tile seams (xs == neighbour's xe + 1); previous row: 8-connectivity
+    for (int j = rowoff[r.y]; j < rowoff[r.y + 1]; j++) {
+      const int o = byrow[j];
+      if (o != i && R[o].xe + 1 == r.xs) uf_union(parent, i, o);
+    }
+    if (r.y > 0)
+      for (int j = rowoff[r.y - 1]; j < rowoff[r.y]; j++) {
+        const int o = byrow[j];
+        const V1Run q = R[o];
+        if (q.xs <= r.xe + 1 && q.xe >= r.xs - 1) uf_union(parent, i, o);
+      }
+  }
+  __syncthreads();
+  // per-blob first-raster maximum and first pixel
+  for (int i = tid; i < n; i += 256) {
+    const int root = uf_find(parent, i);
+    const V1Run r = R[i];
+    const unsigned pos = (unsigned)(r.y * W + r.bx);
+    atomicMax(&best[root], ((unsigned long long)__float_as_uint(r.best) << 32) | (0xffffffffu - pos));
+    atomicMin(&first[root], r.y * W + r.xs);
+    if (root == i) {
+      const int s = atomicAdd(&s_nroot, 1);
+      if (s < kp_cap) roots[s] = i; else *overflow = 1;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int nr = s_nroot < kp_cap ? s_nroot : kp_cap;
+  // findContours list order: reverse raster order of each blob's first pixel
+  for (int i = tid; i < nr; i += 256) {
+    const int me = roots[i];
+    const int fp = __hip_atomic_load(&first[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int rank = 0;
+    for (int j = 0; j < nr; j++)
+      rank += __hip_atomic_load(&first[roots[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > fp;
+    const unsigned long long k = __hip_atomic_load(&best[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned pos = 0xffffffffu - (unsigned)(k & 0xffffffffu);
+    const int y = pos / W, x = pos - y * W;
+    out[rank * 3 + 0] = (float)x;
+    out[rank * 3 + 1] = (float)y;
+    out[rank * 3 + 2] = resize_at(net_out + ((size_t)b * C + part) * hs * ws, hs, ws, W, H, x, y);
+  }
+  if (tid == 0) *out_n = nr;
+}
+
+// ---------------------------------------------------------------------------
+// K-C: getValidPairs.  grid (n_limbs, B), block 256
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void v1_pairs_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
+                                                       int W, int H, V1Model mdl, int kp_cap,
+                                                       const float* __restrict__ kps, const int* __restrict__ n_kps,
+                                                       double* __restrict__ pairs, int* __restrict__ n_pairs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int pa = mdl.pair_parts[2 * k], pb = mdl.pair_parts[2 * k + 1];
+  const int* cnt = n_kps + (size_t)b * mdl.n_parts;
+  const int nA = cnt[pa], nB = cnt[pb];
+  int* out_n = n_pairs + (size_t)b * mdl.n_limbs + k;
+  if (nA == 0 || nB == 0) {
+    if (tid == 0) *out_n = -1;  // "No Connection": invalid pair (utils.py:126-129)
+    return;
+  }
+  int idA0 = 0, idB0 = 0;  // global keypoint ids: running count over parts (skeleton.py:130-133)
+  for (int p = 0; p < pa; p++) idA0 += cnt[p];
+  for (int p = 0; p < pb; p++) idB0 += cnt[p];
+  float* s_pa = smem;
+  float* s_pb = s_pa + hs * ws;
+  const float* gA = net_out + ((size_t)b * C + mdl.mapidx[2 * k]) * hs * ws;
+  const float* gB = net_out + ((size_t)b * C + mdl.mapidx[2 * k + 1]) * hs * ws;
+  for (int i = tid; i < hs * ws; i += 256) {
+    s_pa[i] = gA[i];
+    s_pb[i] = gB[i];
+  }
+  __shared__ int s_wsum[4];
+  __shared__ int s_base;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const float* A = kps + ((size_t)b * mdl.n_parts + pa) * kp_cap * 3;
+  const float* Bk = kps + ((size_t)b * mdl.n_parts + pb) * kp_cap * 3;
+  double* out = pairs + ((size_t)b * mdl.n_limbs + k) * kp_cap * 3;
+  for (int i0 = 0; i0 < nA; i0 += 256) {
+    const int i = i0 + tid;
+    int max_j = -1;
+    double max_score = -1.0;
+    if (i < nA) {
+      const int ax = (int)A[i * 3], ay = (int)A[i * 3 + 1];
+      for (int j = 0; j < nB; j++) {
+        const int bx = (int)Bk[j * 3], by = (int)Bk[j * 3 + 1];
+        const double dx = (double)(bx - ax), dy = (double)(by - ay);
+        const double norm = sqrt(dx * dx + dy * dy);
+        if (norm == 0.0) continue;
+        const double d0 = dx / norm, d1 = dy / norm;
+        const double stepx = dx / 9.0, stepy = dy / 9.0;
+        double total = 0.0;
+        int above = 0;
+        for (int s = 0; s < 10; s++) {
+          const double cx = s == 9 ? (double)bx : (double)s * stepx + (double)ax;
+          const double cy = s == 9 ? (double)by : (double)s * stepy + (double)ay;
+          const int xi = (int)rint(cx), yi = (int)rint(cy);
+          const double va = (double)resize_at(s_pa, hs, ws, W, H, xi, yi);
+          const double vb = (double)resize_at(s_pb, hs, ws, W, H, xi, yi);
+          const double sc = va * d0 + vb * d1;
+          total = total + sc;
+          above += sc > 0.1;
+        }
+        const double avg = total / 10.0;
+        if ((double)above / 10.0 > 0.5 && avg > max_score) {
+          max_j = j;
+          max_score = avg;
+        }
+      }
+    }
+    // ordered compaction of the A's that found a partner
+    const bool found = max_j >= 0;
+    const unsigned long long m = __ballot(found);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) s_wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wsum[w];
+    if (found) {
+      const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+      out[o * 3 + 0] = (double)(idA0 + i);
+      out[o * 3 + 1] = (double)(idB0 + max_j);
+      out[o * 3 + 2] = max_score;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) *out_n = s_base;
+}
+
+// ---------------------------------------------------------------------------
+// K-D: getPersonwiseKeypoints.  grid (B), block 64
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void v1_assemble_kernel(V1Model mdl, int kp_cap, int person_cap,
+                                                         const float* __restrict__ kps,
+                                                         const int* __restrict__ n_kps,
+                                                         const double* __restrict__ pairs,
+                                                         const int* __restrict__ n_pairs,
+                                                         double* __restrict__ persons, int* __restrict__ n_persons,
+                                                         int* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int RW = mdl.n_parts + 1;  // len(body_parts): part slots + total score
+  double* rows = dsm;              // person_cap * RW
+  __shared__ int s_n;
+  __shared__ int s_off[V1_MAX_PARTS + 1];
+  if (lane == 0) {
+    s_n = 0;
+    int acc = 0;
+    for (int p = 0; p < mdl.n_parts; p++) {
+      s_off[p] = acc;
+      acc += n_kps[(size_t)b * mdl.n_parts + p];
+    }
+    s_off[mdl.n_parts] = acc;
+  }
+  __syncthreads();
+  auto kp_score = [&](int id) -> double {  // keypoints_list[id, 2]
+    int p = 0;
+    while (p + 1 < mdl.n_parts && id >= s_off[p + 1]) p++;
+    return (double)kps[((size_t)b * mdl.n_parts + p) * kp_cap * 3 + (id - s_off[p]) * 3 + 2];
+  };
+  for (int k = 0; k < mdl.n_limbs; k++) {
+    const int nc = n_pairs[(size_t)b * mdl.n_limbs + k];
+    if (nc < 0) continue;  // invalid pair
+    const int ia = mdl.pair_parts[2 * k], ib = mdl.pair_parts[2 * k + 1];
+    const double* vp = pairs + ((size_t)b * mdl.n_limbs + k) * kp_cap * 3;
+    for (int i = 0; i < nc; i++) {
+      const double partA = vp[i * 3], partB = vp[i * 3 + 1], sc = vp[i * 3 + 2];
+      const int n = s_n;
+      int hit = -1;
+      for (int r0 = 0; r0 < n && hit < 0; r0 += 64) {
+        const int r = r0 + lane;
+        const unsigned long long m = __ballot(r < n && rows[r * RW + ia] == partA);
+        if (m) hit = r0 + __ffsll((long long)m) - 1;
+      }
+      if (lane == 0) {
+        if (hit >= 0) {
+          rows[hit * RW + ib] = partB;
+          rows[hit * RW + RW - 1] = rows[hit * RW + RW - 1] + (kp_score((int)partB) + sc);
+        } else if (k < mdl.n_parts + 1 - 2) {
+          if (n < person_cap) {
+            double* row = rows + n * RW;
+            for (int q = 0; q < RW; q++) row[q] = -1.0;
+            row[ia] = partA;
+            row[ib] = partB;
+            row[RW - 1] = (kp_score((int)partA) + kp_score((int)partB)) + sc;
+            s_n = n + 1;
+          } else {
+            *overflow = 1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int n = s_n;
+  double* out = persons + (size_t)b * person_cap * RW;
+  for (int i = lane; i < n * RW; i += 64) out[i] = rows[i];
+  if (lane == 0) n_persons[b] = n;
+}
+
+// ---------------------------------------------------------------------------
+// host launcher
+// ---------------------------------------------------------------------------
+int ph_v1_sizes(const V1Model& m, int B, int W, int H, const V1Caps& c, V1Sizes* s) {
+  s->n_runs = (size_t)B * m.n_parts * sizeof(int);
+  s->runs = (size_t)B * m.n_parts * c.run_cap * sizeof(V1Run);
+  s->ws_best = (size_t)B * m.n_parts * c.run_cap * sizeof(unsigned long long);
+  s->ws_first = (size_t)B * m.n_parts * c.run_cap * sizeof(int);
+  s->kps = (size_t)B * m.n_parts * c.kp_cap * 3 * sizeof(float);
+  s->n_kps = (size_t)B * m.n_parts * sizeof(int);
+  s->pairs = (size_t)B * m.n_limbs * c.kp_cap * 3 * sizeof(double);
+  s->n_pairs = (size_t)B * m.n_limbs * sizeof(int);
+  s->persons = (size_t)B * c.person_cap * (m.n_parts + 1) * sizeof(double);
+  s->n_persons = (size_t)B * sizeof(int);
+  return 0;
+}
+
+int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int H, float thr, const V1Model& m,
+                        int B, const V1Caps& c, const V1Buffers& w, hipStream_t stream, hipEvent_t* ev) {
+  if (m.n_parts < 1 || m.n_parts > V1_MAX_PARTS || m.n_limbs < 1 || m.n_limbs > V1_MAX_LIMBS || m.n_parts > C) {
+    ph_set_error("decode_v1: bad model (%d parts, %d limbs, %d channels)", m.n_parts, m.n_limbs, C);
+    return -1;
+  }
+  for (int k = 0; k < 2 * m.n_limbs; k++)
+    if (m.mapidx[k] < 0 || m.mapidx[k] >= C || m.pair_parts[k] < 0 || m.pair_parts[k] >= m.n_parts) {
+      ph_set_error("decode_v1: limb table entry %d out of range", k);
+      return -1;
+    }
+  if (W < 2 || H < 2 || W > 8192 || H > 8192 || (long long)W * H >= 0x7fffffffLL) {
+    ph_set_error("decode_v1: bad image size %dx%d", W, H);
+    return -1;
+  }
+  const size_t ldsA = ((size_t)hs * ws + (size_t)(V1_TILE_H + 2) * (V1_TILE_W + 2) +
+                       (size_t)(V1_TILE_H + 2) * V1_TILE_W + (size_t)V1_TILE_H * V1_TILE_W) * 4;
+  const size_t ldsB = ((size_t)2 * c.run_cap + H + 2 + c.kp_cap) * 4;
+  const size_t ldsC = (size_t)2 * hs * ws * 4;
+  const size_t ldsD = (size_t)c.person_cap * (m.n_parts + 1) * 8;
+  const size_t lim = 160 * 1024 - 2048;
+  if (ldsA > lim || ldsB > lim || ldsC > lim || ldsD > lim) {
+    ph_set_error("decode_v1: LDS budget exceeded (%zu/%zu/%zu/%zu B)", ldsA, ldsB, ldsC, ldsD);
+    return -1;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    PH_CHECK(hipFuncSetAttribute((const void*)v1_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
+    PH_CHECK(hipFuncSetAttribute((const void*)v1_blobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
+    PH_CHECK(hipFuncSetAttribute((const void*)v1_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
+    PH_CHECK(hipFuncSetAttribute((const void*)v1_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lim));
+    attr_done = true;
+  }
+  V1Sizes sz;
+  ph_v1_sizes(m, B, W, H, c, &sz);
+  PH_CHECK(hipMemsetAsync(w.n_runs, 0, sz.n_runs, stream));
+  PH_CHECK(hipMemsetAsync(w.overflow, 0, sizeof(int), stream));
+  PH_CHECK(hipMemsetAsync(w.kps, 0, sz.kps, stream));
+  const int tiles = ((W + V1_TILE_W - 1) / V1_TILE_W) * ((H + V1_TILE_H - 1) / V1_TILE_H);
+  if (ev) PH_CHECK(hipEventRecord(ev[0], stream));
+  hipLaunchKernelGGL(v1_runs_kernel, dim3(tiles, m.n_parts, B), dim3(256), ldsA, stream, net_out, C, hs, ws, W, H, thr,
+                     m.n_parts, c.run_cap, w.n_runs, w.runs, w.overflow);
+  if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
+  hipLaunchKernelGGL(v1_blobs_kernel, dim3(m.n_parts, B), dim3(256), ldsB, stream, net_out, C, hs, ws, W, H, m.n_parts,
+                     c.run_cap, c.kp_cap, (const int*)w.n_runs, (const V1Run*)w.runs, w.ws_best, w.ws_first, w.kps,
+                     w.n_kps, w.overflow);
+  if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
+  hipLaunchKernelGGL(v1_pairs_kernel, dim3(m.n_limbs, B), dim3(256), ldsC, stream, net_out, C, hs, ws, W, H, m,
+                     c.kp_cap, (const float*)w.kps, (const int*)w.n_kps, w.pairs, w.n_pairs);
+  hipLaunchKernelGGL(v1_assemble_kernel, dim3(B), dim3(64), ldsD, stream, m, c.kp_cap, c.person_cap,
+                     (const float*)w.kps, (const int*)w.n_kps, (const double*)w.pairs, (const int*)w.n_pairs,
+                     w.persons, w.n_persons, w.overflow);
+  if (ev) PH_CHECK(hipEventRecord(ev[3], stream));
+  PH_CHECK(hipGetLastError());
+  return 0;
+}

@@ -44,6 +44,11 @@ class PhV2Model(C.Structure):
                 ("pairs", C.c_int * 128), ("mapidx", C.c_int * 128)]
 
 
+class PhV1Model(C.Structure):
+    _fields_ = [("n_parts", C.c_int), ("n_limbs", C.c_int), ("pair_parts", C.c_int * 64),
+                ("mapidx", C.c_int * 64)]
+
+
 # every symbol include/posehip.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
 _fp = C.POINTER(C.c_float)
@@ -79,6 +84,9 @@ SYMBOLS = {
                                    C.POINTER(_vp)]),
     "ph_decode_v2_results": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
     "ph_decode_v2_connections": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "ph_decode_v1": (C.c_int, [_vp, C.POINTER(PhV1Model), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                               _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ph_decode_v1_times": (C.c_int, [_vp, _fp]),
     "ph_decode_v2_times": (C.c_int, [_vp, _fp]),
 }
 
@@ -137,4 +145,18 @@ def v2_model_struct(model):
         m.pairs[2 * k], m.pairs[2 * k + 1] = a, b
     for k, (a, b) in enumerate(model.mapidx):
         m.mapidx[2 * k], m.mapidx[2 * k + 1] = a, b
+    return m
+
+
+def v1_model_struct(body_parts, pose_pairs, mapidx):
+    """The reference's body_parts dict / pose_pairs list / MAPIDX -> PhV1Model."""
+    m = PhV1Model()
+    m.n_parts = len(body_parts) - 1
+    m.n_limbs = len(mapidx)
+    if m.n_limbs > len(pose_pairs) or m.n_limbs > 32 or m.n_parts > 32:
+        raise ValueError("V1 model tables too large / inconsistent")
+    for k in range(m.n_limbs):
+        m.pair_parts[2 * k] = body_parts[pose_pairs[k][0]]
+        m.pair_parts[2 * k + 1] = body_parts[pose_pairs[k][1]]
+        m.mapidx[2 * k], m.mapidx[2 * k + 1] = mapidx[k]
     return m

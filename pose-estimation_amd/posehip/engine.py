@@ -182,6 +182,36 @@ class Engine:
                    "ph_decode_v2_connections")
         return n, idx, sc
 
+    def decode_v1(self, body_parts, pose_pairs, mapidx, B, W0, H0, conf_thres=0.1, kp_cap=256, person_cap=512):
+        """V1 decode of the resident net output -> per frame (keypoints_list f64
+        [K,3], personwise list of f64 rows, extras) exactly as postprocess_multi
+        returns them (openpose/opencv/skeleton.py:154)."""
+        m = _ffi.v1_model_struct(body_parts, pose_pairs, mapidx)
+        P, L = m.n_parts, m.n_limbs
+        n_kps = np.zeros((B, P), np.int32)
+        kps = np.zeros((B, P, kp_cap, 3), np.float32)
+        n_pairs = np.zeros((B, L), np.int32)
+        pairs = np.zeros((B, L, kp_cap, 3), np.float64)
+        n_persons = np.zeros((B,), np.int32)
+        persons = np.zeros((B, person_cap, P + 1), np.float64)
+        _ffi.check(self._lib.ph_decode_v1(self._ctx, C.byref(m), int(B), int(W0), int(H0), float(conf_thres),
+                                          int(kp_cap), int(person_cap), _ptr(n_kps), _ptr(kps), _ptr(n_pairs),
+                                          _ptr(pairs), _ptr(n_persons), _ptr(persons)), "ph_decode_v1")
+        out = []
+        for b in range(B):
+            klist = np.concatenate([kps[b, p, :n_kps[b, p]] for p in range(P)], axis=0).astype(np.float64) \
+                if n_kps[b].sum() else np.zeros((0, 3))
+            people = [persons[b, i].copy() for i in range(n_persons[b])]
+            valid = [pairs[b, k, :n_pairs[b, k]].copy() if n_pairs[b, k] >= 0 else [] for k in range(L)]
+            invalid = [k for k in range(L) if n_pairs[b, k] < 0]
+            out.append((klist, people, dict(n_kps=n_kps[b].copy(), valid_pairs=valid, invalid_pairs=invalid)))
+        return out
+
+    def decode_v1_times(self):
+        ms = (C.c_float * 3)()
+        _ffi.check(self._lib.ph_decode_v1_times(self._ctx, ms), "ph_decode_v1_times")
+        return list(ms)
+
     def decode_v2_times(self):
         ms = (C.c_float * 3)()
         _ffi.check(self._lib.ph_decode_v2_times(self._ctx, ms), "ph_decode_v2_times")
