@@ -57,8 +57,12 @@ struct ph_ctx {
   std::vector<Buf> bufs;
   std::vector<Op> ops;
   int out_c = 0, out_h = 0, out_w = 0;
-  float* net_out = nullptr;
+  float* net_out = nullptr;   // written by the network's fp32 epilogues
   size_t net_out_elems = 0;
+  float* inj_out = nullptr;   // ph_set_net_out's own copy (never aliased by conv epilogues)
+  size_t inj_elems = 0;
+  float* cur_out = nullptr;   // what decode / export read: net_out after a forward, inj_out after an injection
+  size_t cur_elems = 0;
   // injected net output geometry (ph_set_net_out) or the built network's
   int cur_c = 0, cur_h = 0, cur_w = 0;
   uint8_t* frames = nullptr;
@@ -167,6 +171,7 @@ void ph_destroy(ph_ctx* c) {
   for (int i = 0; i < 4; i++)
     if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
   if (c->net_out) (void)hipFree(c->net_out);
+  if (c->inj_out) (void)hipFree(c->inj_out);
   if (c->frames) (void)hipFree(c->frames);
   for (int i = 0; i < 4; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -208,6 +213,10 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
   PH_CHECK(hipSetDevice(c->device));
   PH_CHECK(hipStreamSynchronize(c->stream));
   free_net(c);
+  if (c->cur_out == c->net_out) {  // the old network's output may be reallocated below
+    c->cur_out = nullptr;
+    c->cur_elems = 0;
+  }
   if (batch < 1 || n_bufs < 1 || n_ops < 1) {
     ph_set_error("ph_net_build: bad sizes (batch %d, %d buffers, %d ops)", batch, n_bufs, n_ops);
     return -1;
@@ -378,6 +387,8 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
   }
   c->op_ev.resize(n_ops + 1);
   for (auto& e : c->op_ev) PH_CHECK(hipEventCreate(&e));
+  c->cur_out = c->net_out;
+  c->cur_elems = c->net_out_elems;
   c->cur_c = out_channels;
   c->cur_h = out_h;
   c->cur_w = out_w;
@@ -432,6 +443,8 @@ static int run_ops(ph_ctx* c, int B, bool timed) {
     }
   }
   if (timed) PH_CHECK(hipEventRecord(c->op_ev[c->ops.size()], c->stream));
+  c->cur_out = c->net_out;
+  c->cur_elems = c->net_out_elems;
   c->cur_c = c->out_c;
   c->cur_h = c->out_h;
   c->cur_w = c->out_w;
@@ -465,16 +478,16 @@ double ph_op_flops(ph_ctx* c, int op) {
 int ph_get_net_out(ph_ctx* c, int B, float* host_out) {
   PH_CHECK(hipSetDevice(c->device));
   const size_t n = (size_t)B * c->cur_c * c->cur_h * c->cur_w;
-  if (!c->net_out || n > c->net_out_elems) {
+  if (!c->cur_out || n > c->cur_elems) {
     ph_set_error("ph_get_net_out: no net output for batch %d", B);
     return -1;
   }
-  PH_CHECK(hipMemcpyAsync(host_out, c->net_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  PH_CHECK(hipMemcpyAsync(host_out, c->cur_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   PH_CHECK(hipStreamSynchronize(c->stream));
   return 0;
 }
 
-float* ph_net_out_dev(ph_ctx* c) { return c->net_out; }
+float* ph_net_out_dev(ph_ctx* c) { return c->cur_out; }
 
 int ph_set_net_out(ph_ctx* c, const float* src, int on_device, int B, int C, int Hs, int Ws) {
   PH_CHECK(hipSetDevice(c->device));
@@ -483,18 +496,22 @@ int ph_set_net_out(ph_ctx* c, const float* src, int on_device, int B, int C, int
     return -1;
   }
   const size_t n = (size_t)B * C * Hs * Ws;
-  if (!c->ops.empty() && n > c->net_out_elems) {
-    ph_set_error("ph_set_net_out: %zu elements exceed the built network's output (%zu)", n, c->net_out_elems);
-    return -1;  // conv epilogues hold the pointer; do not reallocate under them
+  if (n > c->inj_elems) {
+    PH_CHECK(hipStreamSynchronize(c->stream));
+    if (c->inj_out) PH_CHECK(hipFree(c->inj_out));
+    c->inj_out = nullptr;
+    c->inj_elems = 0;
+    PH_CHECK(hipMalloc(&c->inj_out, n * sizeof(float)));
+    c->inj_elems = n;
   }
-  if (ensure_net_out(c, n)) return -1;
-  PH_CHECK(hipMemcpyAsync(c->net_out, src, n * sizeof(float),
+  PH_CHECK(hipMemcpyAsync(c->inj_out, src, n * sizeof(float),
                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
   if (!on_device) PH_CHECK(hipStreamSynchronize(c->stream));
+  c->cur_out = c->inj_out;
+  c->cur_elems = c->inj_elems;
   c->cur_c = C;
   c->cur_h = Hs;
   c->cur_w = Ws;
-  if (B > c->batch) c->batch = c->ops.empty() ? B : c->batch;
   return 0;
 }
 
@@ -511,15 +528,15 @@ int ph_get_buffer(ph_ctx* c, int buf, uint16_t* host_out, int64_t n_elems) {
 
 int ph_upsample_maps(ph_ctx* c, int frame, int c0, int nc, int Ht, int Wt, float* host_out) {
   PH_CHECK(hipSetDevice(c->device));
-  if (!c->net_out || frame < 0 || c0 < 0 || nc < 1 || c0 + nc > c->cur_c || Ht < 1 || Wt < 1 ||
-      (size_t)(frame + 1) * c->cur_c * c->cur_h * c->cur_w > c->net_out_elems) {
+  if (!c->cur_out || frame < 0 || c0 < 0 || nc < 1 || c0 + nc > c->cur_c || Ht < 1 || Wt < 1 ||
+      (size_t)(frame + 1) * c->cur_c * c->cur_h * c->cur_w > c->cur_elems) {
     ph_set_error("ph_upsample_maps: bad frame/channel window");
     return -1;
   }
   float* tmp = nullptr;
   const size_t n = (size_t)nc * Ht * Wt;
   PH_CHECK(hipMalloc(&tmp, n * sizeof(float)));
-  const float* planes = c->net_out + ((size_t)frame * c->cur_c + c0) * c->cur_h * c->cur_w;
+  const float* planes = c->cur_out + ((size_t)frame * c->cur_c + c0) * c->cur_h * c->cur_w;
   int rc = ph_launch_upsample_maps(planes, c->cur_h, c->cur_w, Ht, Wt, nc, tmp, c->stream);
   if (!rc && hipMemcpyAsync(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -1;
   if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
@@ -531,7 +548,7 @@ int ph_upsample_maps(ph_ctx* c, int frame, int c0, int nc, int Ht, int Wt, float
 int ph_argmax_maps(ph_ctx* c, int B, float* vals_host, int32_t* locs_host) {
   PH_CHECK(hipSetDevice(c->device));
   const int n_maps = B * c->cur_c, n = c->cur_h * c->cur_w;
-  if (!c->net_out || B < 1 || (size_t)n_maps * n > c->net_out_elems) {
+  if (!c->cur_out || B < 1 || (size_t)n_maps * n > c->cur_elems) {
     ph_set_error("ph_argmax_maps: no net output for batch %d", B);
     return -1;
   }
@@ -539,7 +556,7 @@ int ph_argmax_maps(ph_ctx* c, int B, float* vals_host, int32_t* locs_host) {
   int* dl = nullptr;
   PH_CHECK(hipMalloc(&dv, n_maps * sizeof(float)));
   PH_CHECK(hipMalloc(&dl, n_maps * sizeof(int)));
-  int rc = ph_launch_argmax_maps(c->net_out, n_maps, n, dv, dl, c->stream);
+  int rc = ph_launch_argmax_maps(c->cur_out, n_maps, n, dv, dl, c->stream);
   if (!rc && hipMemcpyAsync(vals_host, dv, n_maps * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -1;
   if (!rc && hipMemcpyAsync(locs_host, dl, n_maps * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -1;
   if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
@@ -552,11 +569,11 @@ int ph_argmax_maps(ph_ctx* c, int B, float* vals_host, int32_t* locs_host) {
 // ---- V2 decode ---------------------------------------------------------------
 static int v2_prepare(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, int max_people, PhV2Dev* dev) {
   PH_CHECK(hipSetDevice(c->device));
-  if (!m || B < 1 || max_people < 1 || !c->net_out) {
+  if (!m || B < 1 || max_people < 1 || !c->cur_out) {
     ph_set_error("ph_decode_v2: bad args or no net output");
     return -1;
   }
-  if ((size_t)B * c->cur_c * c->cur_h * c->cur_w > c->net_out_elems) {
+  if ((size_t)B * c->cur_c * c->cur_h * c->cur_w > c->cur_elems) {
     ph_set_error("ph_decode_v2: batch %d exceeds the resident net output", B);
     return -1;
   }
@@ -611,7 +628,7 @@ int ph_decode_v2_dev(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, flo
                      int32_t** n_people_dev, float** keypoints_dev, float** scores_dev) {
   PhV2Dev dev;
   if (v2_prepare(c, m, B, Ht, Wt, max_people, &dev)) return -1;
-  if (ph_launch_decode_v2(c->net_out, c->cur_c, c->cur_h, c->cur_w, Ht, Wt, dev, B, scale, max_people, c->v2,
+  if (ph_launch_decode_v2(c->cur_out, c->cur_c, c->cur_h, c->cur_w, Ht, Wt, dev, B, scale, max_people, c->v2,
                           c->stream, c->ev))
     return -1;
   if (n_people_dev) *n_people_dev = c->v2.n_people;
@@ -672,8 +689,8 @@ int ph_decode_v1(ph_ctx* c, const ph_v1_model* m, int B, int W0, int H0, float c
                  int person_cap, int32_t* n_kps, float* kps, int32_t* n_pairs, double* pairs, int32_t* n_persons,
                  double* persons) {
   PH_CHECK(hipSetDevice(c->device));
-  if (!m || B < 1 || kp_cap < 1 || person_cap < 1 || !c->net_out ||
-      (size_t)B * c->cur_c * c->cur_h * c->cur_w > c->net_out_elems) {
+  if (!m || B < 1 || kp_cap < 1 || person_cap < 1 || !c->cur_out ||
+      (size_t)B * c->cur_c * c->cur_h * c->cur_w > c->cur_elems) {
     ph_set_error("ph_decode_v1: bad args or no net output for batch %d", B);
     return -1;
   }
@@ -710,7 +727,7 @@ int ph_decode_v1(ph_ctx* c, const ph_v1_model* m, int B, int W0, int H0, float c
     PH_CHECK(hipMalloc(&c->v1.overflow, sizeof(int)));
     c->v1_key = key;
   }
-  if (ph_launch_decode_v1(c->net_out, c->cur_c, c->cur_h, c->cur_w, W0, H0, conf_thres, dev, B, caps, c->v1,
+  if (ph_launch_decode_v1(c->cur_out, c->cur_c, c->cur_h, c->cur_w, W0, H0, conf_thres, dev, B, caps, c->v1,
                           c->stream, c->ev1))
     return -1;
   hipStream_t s = c->stream;

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Regenerates the committed golden fixtures (run in the BUILD container only).
+
+  tables_ref.json      COLORS / MAPIDX / COCO+MPI body_parts and pose_pairs read
+                       from the REFERENCE file openpose/opencv/common.py (pure
+                       constants; loaded by path so the package __init__, which
+                       imports cv2, is not executed).
+  v2_scenes.npz        seeded synthetic BODY_25 / COCO net outputs and the V2
+  v1_scenes.npz        / V1 oracle's outputs for them (inputs + expected outputs;
+                       produced by oracle/*.py, NOT by the reference, which cannot
+                       run offline -- SURVEY 8c).
+  ref_predictions_native.txt  is a verbatim copy of the reference's only stored
+                       result, data/test/output/inference_native/predictions.txt.
+"""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "pose-estimation_amd"))
+
+
+def tables():
+    path = "/root/reference/openpose/opencv/common.py"
+    spec = importlib.util.spec_from_file_location("ref_common", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {"COLORS": mod.COLORS, "MAPIDX": mod.MAPIDX}
+    for ds in ("COCO", "MPI"):
+        bp, pp = mod.get_body_parts_and_pose_pairs(ds)
+        out[ds] = {"body_parts": bp, "pose_pairs": pp}
+    with open(os.path.join(HERE, "tables_ref.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def v2():
+    from oracle import decode_v2
+    from posehip import synth
+    from posehip.tables import BODY_25, COCO_18
+    out = {}
+    for tag, model, hs, ws, P, seed in (("b25_p3", BODY_25, 46, 82, 3, 501), ("b25_p0", BODY_25, 46, 82, 0, 502),
+                                         ("b25_sq_p2", BODY_25, 46, 46, 2, 503), ("coco_p4", COCO_18, 46, 82, 4, 504)):
+        net = synth.synth_net_output(seed, P, model, hs, ws)
+        kp, sc, inter = decode_v2.decode(net, model, hs * 8, ws * 8, 1.0, return_intermediates=True)
+        out[tag + "_net"] = net.astype(np.float16)          # halves the fixture; decoded from this exact input
+        net = out[tag + "_net"].astype(np.float32)
+        kp, sc, inter = decode_v2.decode(net, model, hs * 8, ws * 8, 1.0, return_intermediates=True)
+        out[tag + "_kp"], out[tag + "_sc"] = kp, sc
+        out[tag + "_peaks_n"] = inter["peaks"][:, 0, 0].astype(np.int32)
+        rows = inter["rows"][inter["valid"]] if len(inter["valid"]) else np.zeros((0, model.n_parts + 1), np.int32)
+        out[tag + "_rows"] = rows
+    np.savez_compressed(os.path.join(HERE, "v2_scenes.npz"), **out)
+
+
+def v1():
+    from oracle import decode_v1
+    from posehip import synth
+    from posehip.tables import COCO_18, MAPIDX, get_body_parts_and_pose_pairs
+    bp, pp = get_body_parts_and_pose_pairs("COCO")
+    out = {}
+    for tag, hs, ws, W, H, P, seed in (("p3_480", 46, 46, 480, 480, 3, 601), ("p4_656", 46, 82, 656, 368, 4, 602),
+                                        ("p2_1080", 46, 82, 1920, 1080, 2, 603)):
+        net = synth.synth_net_output(seed, P, COCO_18, hs, ws).astype(np.float16)
+        pred = net.astype(np.float32)[None]
+        kl, people, _ = decode_v1.postprocess_multi(pred, bp, pp, MAPIDX, W, H, 0.1, True)
+        out[tag + "_net"] = net
+        out[tag + "_size"] = np.array([W, H], np.int32)
+        out[tag + "_kl"] = kl
+        out[tag + "_people"] = np.stack(people) if people else np.zeros((0, 19))
+    np.savez_compressed(os.path.join(HERE, "v1_scenes.npz"), **out)
+
+
+if __name__ == "__main__":
+    tables()
+    v2()
+    v1()
+    print("golden fixtures written to", HERE)

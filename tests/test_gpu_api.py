@@ -1,0 +1,189 @@
+"""GPU: the estimator classes that keep the reference's interface, end to end
+through the C ABI, plus the committed golden scenes."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+
+from posehip import _ffi, api_native, api_opencv, caffe_io, graph, synth, tables
+from posehip.tables import BODY_25, COCO_18, MAPIDX
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("tag,model", [("b25_p3", BODY_25), ("b25_p0", BODY_25), ("b25_sq_p2", BODY_25),
+                                       ("coco_p4", COCO_18)])
+def test_golden_v2(engine, tag, model):
+    g = np.load(os.path.join(G, "v2_scenes.npz"))
+    net = g[tag + "_net"].astype(np.float32)
+    engine.set_net_out(net[None])
+    res, ex = engine.decode_v2(model, 1, net.shape[1] * 8, net.shape[2] * 8, want_peaks=True, want_subsets=True)
+    np.testing.assert_array_equal(res[0][0], g[tag + "_kp"])
+    np.testing.assert_array_equal(res[0][1], g[tag + "_sc"])
+    np.testing.assert_array_equal(ex["peaks"][0, :, 0, 0].astype(np.int32), g[tag + "_peaks_n"])
+    np.testing.assert_array_equal(ex["subsets"][0, :len(g[tag + "_rows"])], g[tag + "_rows"])
+
+
+@pytest.mark.parametrize("tag", ["p3_480", "p4_656", "p2_1080"])
+def test_golden_v1(engine, tag):
+    g = np.load(os.path.join(G, "v1_scenes.npz"))
+    bp, pp = tables.get_body_parts_and_pose_pairs("COCO")
+    W, H = (int(v) for v in g[tag + "_size"])
+    engine.set_net_out(g[tag + "_net"].astype(np.float32)[None])
+    kl, people, _ = engine.decode_v1(bp, pp, MAPIDX, 1, W, H, 0.1)[0]
+    np.testing.assert_array_equal(kl, g[tag + "_kl"])
+    np.testing.assert_array_equal(np.stack(people) if people else np.zeros((0, 19)), g[tag + "_people"])
+
+
+def test_native_estimator_end_to_end(tmp_path):
+    """PyOpenPoseNative.predict / filter_prediction / predict_hm / predict_from_hm /
+    predict_batch with the same call sequence as openpose/native/python/test.py."""
+    params = dict(model_folder="/nonexistent/", model_pose="BODY_25", net_resolution="-1x128",
+                  posehip_random_weights=0)
+    pyop = api_native.PyOpenPoseNative(params, 0.0, 2, 2)
+    assert pyop.params["disable_blending"] is True and pyop.params["scale_number"] == 1
+    img = synth.synth_frames(0, 1, 96, 160)[0]
+    pyop.predict(img)
+    pyop.filter_prediction()
+    assert pyop.datum.netInputSizes[0].x == 224 and pyop.datum.netInputSizes[0].y == 128   # 128*160/96=213.3 -> 224
+    assert pyop.opencv_image.shape == img.shape
+    if pyop.pose_empty:
+        assert pyop.pose_scores is None and pyop.pose_bounding_box is None
+    else:
+        assert pyop.pose_keypoints.shape[1:] == (25, 3) and pyop.pose_scores.ndim == 1
+        assert pyop.pose_bounding_box.shape == (len(pyop.pose_scores), 4)
+        assert "/" in pyop.filtered_skel
+    # raw heat maps -> .float file -> decode-only entry gives the same people
+    hm_path = str(tmp_path / "hm" / "f0.float")
+    pyop.predict_hm(img, hm_path)
+    kp0 = None if pyop.pose_empty else pyop.pose_keypoints.copy()
+    hm = api_native.read_heatmap_file(hm_path)
+    assert hm[0].shape == (1, 78, 16, 28)
+    pyop.predict_from_hm(img, hm)
+    kp1 = None if pyop.pose_empty else pyop.pose_keypoints
+    assert (kp0 is None) == (kp1 is None)
+    if kp0 is not None:
+        np.testing.assert_array_equal(kp0, kp1)
+    # injected synthetic people: decode-only path finds them and scales to image pixels
+    scene = synth.synth_net_output(5, 2, BODY_25, 46, 82)[None]
+    big = np.zeros((736, 1312, 3), np.uint8)
+    pyop.predict_from_hm(big, [scene])
+    assert not pyop.pose_empty and len(pyop.pose_scores) >= 1
+    assert pyop.pose_keypoints[..., 0].max() > 656 * 0.9      # x scaled by (1312-1)/(656-1) ~ 2
+    # batch == sequential
+    frames = synth.synth_frames(1, 3, 96, 160)
+    batch = pyop.predict_batch(list(frames))
+    for f, (kp, sc) in zip(frames, batch):
+        pyop.predict(f)
+        if kp is None:
+            assert pyop.pose_empty
+        else:
+            np.testing.assert_array_equal(pyop.pose_keypoints, kp)
+    pyop.opWrapper.close()
+    with pytest.raises(FileNotFoundError):
+        api_native.PyOpenPoseNative(dict(model_folder="/nonexistent/", model_pose="BODY_25"))
+
+
+def test_extractor_and_csv(tmp_path):
+    args = argparse.Namespace(op_model_folder="/nonexistent/", op_model_pose="BODY_25", op_net_resolution="-1x64",
+                              op_heatmaps_add_parts=True, op_heatmaps_add_bkg=True, op_heatmaps_add_PAFs=True,
+                              op_heatmaps_scale=1, op_display=1, op_skel_thres=0.0, op_max_true_body=8,
+                              op_patch_offset=2, posehip_random_weights=1)
+    pe = api_native.OpenPosePoseExtractor(args)
+    img = synth.synth_frames(2, 1, 64, 64)[0]
+    out = str(tmp_path / "skel" / "0.txt")
+    pe.predict(img, None, kpt_save_path=out)
+    assert os.path.exists(out)
+    hm = pe.pyop.datum.poseHeatMaps
+    assert hm.shape == (78, 64, 64)                                  # parts + bkg + PAFs at net-input size
+    if not pe.pyop.pose_empty:
+        assert pe.pyop.pose_heatmaps.shape == (64, 64, 78)            # HWC view the tracker crops (track.py)
+    ok, image = pe.display("w", scale=1.0, image=img)
+    assert ok and image.shape[1] == 64
+    pe.pyop.opWrapper.close()
+
+
+def test_opencv_estimator_end_to_end():
+    """PyOpenPoseOpenCV.load / predict / postprocess_* as in openpose/opencv/inference.py:57-77."""
+    from oracle import decode_v1, net_ref
+    bp, pp = tables.get_body_parts_and_pose_pairs("COCO")
+    pyop = api_opencv.PyOpenPoseOpenCV(64, 48, bp, pp)
+    pyop.load("/nonexistent.prototxt", "/nonexistent.caffemodel", False, random_weights=3)
+    img = synth.synth_frames(3, 1, 60, 80)[0]                       # resized 80x60 -> 64x48 by the preprocess kernel
+    pred = pyop.predict(img)
+    assert pred.shape == (1, 57, 6, 8) and pred.dtype == np.float32
+    assert (pyop.original_image_width, pyop.original_image_height) == (80, 60)
+    t, _ = pyop.net.getPerfProfile()
+    assert t > 0
+    pts = pyop.postprocess_single(pred)
+    assert pts == decode_v1.postprocess_single(pred, 19, 80, 60, 0.1)
+    kl, people = pyop.postprocess_multi(pred)
+    rk, rp = decode_v1.postprocess_multi(pred, bp, pp, MAPIDX, 80, 60, 0.1)
+    np.testing.assert_array_equal(kl, rk)
+    assert len(people) == len(rp)
+    # synthetic people through the same class: the decode works on any [1,57,h,w] prediction
+    pyop.original_image_width, pyop.original_image_height = 480, 480
+    scene = synth.synth_net_output(9, 3, COCO_18, 46, 46)[None]
+    kl, people = pyop.postprocess_multi(scene)
+    rk, rp = decode_v1.postprocess_multi(scene, bp, pp, MAPIDX, 480, 480, 0.1)
+    np.testing.assert_array_equal(kl, rk)
+    for a, b in zip(people, rp):
+        np.testing.assert_array_equal(a, b)
+    assert len(people) >= 2
+    out = pyop.draw_skeleton(personwise_keypoints=people, keypoints_list=kl, image=np.zeros((480, 480, 3), np.uint8))
+    assert out.any()
+    pyop.net.engine.close()
+
+
+def test_preprocess_modes_match_restated_cv2(engine):
+    """K1: u8 HWC BGR -> bf16 NHWC input; integer fixed-point bilinear of the
+    blobFromImage resize is bit-exact against a NumPy restatement."""
+    net = caffe_io.parse_prototxt('input: "image" input_dim: 1 input_dim: 3 input_dim: 24 input_dim: 40\n' +
+                                  caffe_io._conv("out", "image", 8, 3))
+    plan = graph.build_plan(net, graph.random_weights(net, 0))
+    engine.build(plan, 2)
+    frames = synth.synth_frames(4, 2, 24, 40)
+    engine.preprocess(frames, _ffi.PH_PRE_CV2)                       # same size: pure x/255
+    buf = engine.get_buffer(0)                                       # [B, H+2, W+2, 8]
+    want = (frames.astype(np.float32) * np.float32(1 / 255.0))
+    want16 = (want.view(np.uint32) + 0x7fff + ((want.view(np.uint32) >> 16) & 1)) >> 16 << 16
+    np.testing.assert_array_equal(buf[:, 1:-1, 1:-1, :3].view(np.uint32), want16.astype(np.uint32))
+    assert (buf[:, 0] == 0).all() and (buf[:, :, 0] == 0).all() and (buf[..., 3:] == 0).all()   # zero border + pad
+    big = synth.synth_frames(5, 2, 51, 77)
+    engine.preprocess(big, _ffi.PH_PRE_CV2)
+    got = engine.get_buffer(0)[:, 1:-1, 1:-1, :3]
+    ref = _cv_resize_u8(big, 40, 24).astype(np.float32) * np.float32(1 / 255.0)
+    ref16 = ((ref.view(np.uint32) + 0x7fff + ((ref.view(np.uint32) >> 16) & 1)) >> 16 << 16).astype(np.uint32)
+    np.testing.assert_array_equal(got.view(np.uint32), ref16)
+    engine.preprocess(big, _ffi.PH_PRE_NATIVE)                       # keep-aspect, x/256-0.5, zero fill -> -0.5
+    nat = engine.get_buffer(0)[:, 1:-1, 1:-1, :3]
+    assert nat.min() >= -0.5 and nat.max() <= 0.5
+    s = min(39 / 76, 23 / 50)
+    assert (nat[:, :, int(77 * s) + 2:] == -0.5).all()               # right of the scaled image: filled with 0 -> -0.5
+
+
+def _cv_resize_u8(img, W, H):
+    """OpenCV 4.5 resize INTER_LINEAR on uint8 (11-bit fixed point), restated."""
+    B, H0, W0, _ = img.shape
+    def coords(n_dst, n_src, clamp_reset):
+        d = np.arange(n_dst, dtype=np.float64)
+        f = ((d + 0.5) * (n_src / n_dst) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int32)
+        f = (f - s).astype(np.float32)
+        if clamp_reset:
+            lo, hi = s < 0, s >= n_src - 1
+            f[lo] = 0; s[lo] = 0; f[hi] = 0; s[hi] = n_src - 1
+        c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int32)
+        c1 = np.rint(f * np.float32(2048)).astype(np.int32)
+        return s, c0, c1
+    sx, a0, a1 = coords(W, W0, True)
+    sy, b0, b1 = coords(H, H0, False)
+    sx1 = np.minimum(sx + 1, W0 - 1)
+    sy0, sy1 = np.clip(sy, 0, H0 - 1), np.clip(sy + 1, 0, H0 - 1)
+    im = img.astype(np.int32)
+    rows = im[:, :, sx] * a0[None, None, :, None] + im[:, :, sx1] * a1[None, None, :, None]
+    S0, S1 = rows[:, sy0], rows[:, sy1]
+    d = (((b0[None, :, None, None] * (S0 >> 4)) >> 16) + ((b1[None, :, None, None] * (S1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(d, 0, 255).astype(np.uint8)

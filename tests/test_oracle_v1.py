@@ -1,0 +1,134 @@
+"""CPU: the V1 oracle (transcription of openpose/opencv/utils.py + restated cv2
+primitives) against known-answer cases and the golden scenes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import decode_v1
+from posehip import tables
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+BP, PP = tables.get_body_parts_and_pose_pairs("COCO")
+
+
+def test_tables_equal_reference_common_py():
+    ref = json.load(open(os.path.join(G, "tables_ref.json")))
+    assert tables.COLORS == ref["COLORS"] and tables.MAPIDX == ref["MAPIDX"]
+    for ds in ("COCO", "MPI"):
+        bp, pp = tables.get_body_parts_and_pose_pairs(ds)
+        assert bp == ref[ds]["body_parts"] and pp == ref[ds]["pose_pairs"]
+    assert len(tables.MAPIDX) == 16 and len(PP) == 17          # LEye->LEar is never decoded (Appendix B.1)
+    with pytest.raises(Exception):
+        tables.get_body_parts_and_pose_pairs("BODY_25")
+
+
+def test_resize_linear_kats():
+    ramp = np.tile(np.arange(4, dtype=np.float32), (4, 1))
+    up = decode_v1.resize_linear(ramp, 8, 8)
+    np.testing.assert_allclose(up[0], [0, 0.25, 0.75, 1.25, 1.75, 2.25, 2.75, 3], atol=1e-6)   # half-pixel centres
+    assert (up == up[0]).all()
+    same = decode_v1.resize_linear(ramp, 4, 4)
+    np.testing.assert_array_equal(same, ramp)                                               # identity
+    rng = np.random.default_rng(1)
+    m = rng.normal(size=(46, 82)).astype(np.float32)
+    full = decode_v1.resize_linear(m, 1920, 1080)                                            # anisotropic 23.4x/23.5x
+    xs, ys = np.array([0, 5, 1919, 960, 1234]), np.array([0, 1079, 1079, 540, 77])
+    np.testing.assert_array_equal(decode_v1.resize_linear_at(m, 1920, 1080, xs, ys), full[ys, xs])
+
+
+def test_gaussian3_reflect101():
+    m = np.zeros((5, 6), np.float32)
+    m[0, 0] = 16
+    g = decode_v1.gaussian3(m)
+    np.testing.assert_array_equal(g[:2, :2], [[4, 2], [2, 1]])   # corner impulse: 101-reflection does not repeat the edge
+    assert g.sum() == 9 and g[2:].sum() == 0
+    m = np.zeros((5, 6), np.float32)
+    m[1, 1] = 16
+    np.testing.assert_array_equal(decode_v1.gaussian3(m)[:3, :3], [[4, 4, 2], [4, 4, 2], [2, 2, 1]])  # tap at -1 -> +1
+    m = np.zeros((5, 6), np.float32)
+    m[2, 3] = 16
+    np.testing.assert_array_equal(decode_v1.gaussian3(m)[1:4, 2:5], [[1, 2, 1], [2, 4, 2], [1, 2, 1]])
+
+
+def test_blob_peaks_order_ties_and_score_source():
+    m = np.zeros((40, 60), np.float32)
+    m[5, 5] = 1.0
+    m[30, 40] = 0.8
+    m[30, 42] = 0.8            # merges with its twin after the blur; first raster max wins
+    kps = decode_v1.blob_peaks(m, 0.1)
+    assert [(k[0], k[1]) for k in kps] == [(40, 30), (5, 5)]    # findContours order: last blob first;
+    assert kps[0][2] == np.float32(0.8) and kps[1][2] == 1.0    # smoothed tie (40 vs 41): first raster wins
+    ring = np.zeros((20, 20), np.float32)
+    ring[9, 10] = ring[11, 10] = ring[10, 9] = ring[10, 11] = 0.5
+    (x, y, s), = decode_v1.blob_peaks(ring, 0.1)
+    assert (x, y) == (10, 10) and s == 0.0   # score is read from the UN-smoothed map at the smoothed arg-max (utils.py:22)
+    assert decode_v1.blob_peaks(np.full((8, 8), 0.1, np.float32), 0.1) == []   # strict >
+
+
+def test_rounding_never_hits_a_tie():
+    """Samples are a + k*(b-a)/9 with integer a,b: never on a half-integer, so
+    banker's rounding (utils.py:91-94) == any round-to-nearest."""
+    d = np.arange(-2048, 2049)[:, None].astype(np.float64)
+    k = np.arange(10)[None, :].astype(np.float64)
+    x = k * (d / 9.0)
+    frac = np.abs(x - np.floor(x) - 0.5)
+    assert frac.min() > 1.0 / 19
+
+
+def _pred_with_limb(ax, ay, bx, by, hs=46, ws=46):
+    pred = np.zeros((1, 57, hs, ws), np.float32)
+    d = np.array([bx - ax, by - ay], np.float64)
+    d /= np.linalg.norm(d)
+    pred[0, tables.MAPIDX[0][0]] = d[0]
+    pred[0, tables.MAPIDX[0][1]] = d[1]
+    return pred
+
+
+def test_valid_pairs_rules():
+    pred = _pred_with_limb(10, 10, 30, 10)
+    det = [[] for _ in range(18)]
+    det[1] = [(10, 10, 0.9, 0), (10, 40, 0.8, 1)]               # two necks
+    det[2] = [(30, 10, 0.7, 2), (10, 10, 0.6, 3)]               # RShoulder candidates; the 2nd coincides with neck 0
+    vp, inv = decode_v1.get_valid_pairs(pred, det, PP, BP, 46, 46, tables.MAPIDX)
+    assert inv == list(range(1, 16))                            # limbs with an empty side are "invalid"
+    rows = vp[0]
+    # neck 0 -> shoulder 2 with score 1 (zero-length candidate skipped); neck 1 also claims a shoulder:
+    # no uniqueness constraint on B (Appendix B.4)
+    assert rows.shape[1] == 3 and rows[0, 0] == 0 and rows[0, 1] == 2 and abs(rows[0, 2] - 1.0) < 1e-6
+    assert all(r[1] in (2, 3) for r in rows)
+    # both sides present but PAF opposes -> empty [0,3] array, NOT invalid (Appendix B.5)
+    vp, inv = decode_v1.get_valid_pairs(-pred, det, PP, BP, 46, 46, tables.MAPIDX)
+    assert 0 not in inv and vp[0].shape == (0, 3)
+
+
+def test_personwise_rules():
+    kl = np.array([[0, 0, .9], [0, 0, .8], [0, 0, .7], [0, 0, .6]])
+    vp = [np.zeros((0, 3)) for _ in range(16)]
+    vp[0] = np.array([[0., 2., 0.5]])                           # Neck0 - RShoulder2
+    vp[2] = np.array([[2., 3., 0.25]])                          # RShoulder2 - RElbow3: extends person 0
+    vp[1] = np.array([[1., 3., 0.1]])                           # Neck1 - LShoulder(3): new person
+    people = decode_v1.get_personwise_keypoints(vp, [], kl, BP, PP, tables.MAPIDX)
+    assert len(people) == 2
+    assert people[0][1] == 0 and people[0][2] == 2 and people[0][3] == 3
+    assert people[0][-1] == pytest.approx((.9 + .7 + .5) + (.6 + .25))
+    assert people[1][1] == 1 and people[1][5] == 3 and (people[1] == -1).sum() == 16
+
+
+def test_postprocess_single():
+    pred = np.zeros((1, 19, 46, 46), np.float32)
+    pred[0, 0, 10, 20] = 0.9
+    pred[0, 1, 5, 5] = 0.05
+    pts = decode_v1.postprocess_single(pred, 19, 480, 368, 0.1)
+    assert pts[0] == (int(480 * 20 / 46), int(368 * 10 / 46)) and pts[1] is None
+
+
+@pytest.mark.parametrize("tag", ["p3_480", "p4_656", "p2_1080"])
+def test_golden_scenes(tag):
+    g = np.load(os.path.join(G, "v1_scenes.npz"))
+    pred = g[tag + "_net"].astype(np.float32)[None]
+    W, H = (int(v) for v in g[tag + "_size"])
+    kl, people = decode_v1.postprocess_multi(pred, BP, PP, tables.MAPIDX, W, H, 0.1)
+    np.testing.assert_array_equal(kl, g[tag + "_kl"])
+    np.testing.assert_array_equal(np.stack(people) if people else np.zeros((0, 19)), g[tag + "_people"])

@@ -1,0 +1,153 @@
+"""CPU: the V2 oracle against known-answer cases, the committed golden scenes and
+the one result artefact the reference holds (predictions.txt)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import decode_v2
+from posehip.tables import BODY_25, COCO_18
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_bicubic_kats():
+    c = np.full((3, 5, 7), 0.25, np.float32)
+    up = decode_v2.upsample_bicubic(c, 40, 56)
+    assert np.allclose(up, 0.25, atol=1e-6)                     # partition of unity
+    ramp = np.tile(np.arange(8, dtype=np.float32), (6, 1))
+    up = decode_v2.upsample_bicubic(ramp, 48, 64)
+    xs = (np.arange(64) + 0.5) / 8 - 0.5
+    inner = (xs >= 1) & (xs <= 6)
+    assert np.allclose(up[10, inner], xs[inner], atol=1e-5)     # Catmull-Rom reproduces linear ramps
+    # single pixel == full map (the kernels sample single pixels)
+    rng = np.random.default_rng(0)
+    m = rng.normal(size=(1, 9, 11)).astype(np.float32)
+    full = decode_v2.upsample_bicubic(m, 72, 88)
+    x0, x1, x2, x3, dx = decode_v2._src_coords(88, 11)
+    y0, y1, y2, y3, dy = decode_v2._src_coords(72, 9)
+    for (y, x) in [(0, 0), (71, 87), (35, 40), (3, 86)]:
+        t = [decode_v2._cubic(m[0, r, x0[x]], m[0, r, x1[x]], m[0, r, x2[x]], m[0, r, x3[x]], dx[x])
+             for r in (y0[y], y1[y], y2[y], y3[y])]
+        assert decode_v2._cubic(t[0], t[1], t[2], t[3], dy[y]) == full[0, y, x]
+
+
+def test_nms_kats():
+    up = np.zeros((1, 20, 30), np.float32)
+    up[0, 5, 5] = 0.9            # isolated peak
+    up[0, 0, 10] = 0.9           # on the border: excluded
+    up[0, 10, 10] = up[0, 10, 11] = 0.5    # plateau: strict > never fires
+    up[0, 15, 20] = 0.04         # below threshold
+    up[0, 12, 25] = 0.3
+    pk = decode_v2.nms(up, 0.05, 127)
+    assert pk[0, 0, 0] == 2
+    assert tuple(pk[0, 1]) == (5.5, 5.5, np.float32(0.9))       # +0.5 offset, raster order
+    assert tuple(pk[0, 2]) == (25.5, 12.5, np.float32(0.3))
+    # truncation keeps the first max_peaks in raster order
+    many = np.zeros((1, 40, 40), np.float32)
+    many[0, 4:36:8, 4:36:8] = np.linspace(0.1, 1.0, 16).reshape(4, 4)
+    pk = decode_v2.nms(many, 0.05, 10)
+    assert pk[0, 0, 0] == 10
+    assert list(pk[0, 1:, 1]) == [4.5] * 4 + [12.5] * 4 + [20.5] * 2    # first 10 of 16 in raster order
+    # 7x7 centroid pulls towards a heavier neighbour
+    two = np.zeros((1, 20, 20), np.float32)
+    two[0, 10, 10], two[0, 10, 12] = 1.0, 0.5
+    pk = decode_v2.nms(two, 0.05, 127)
+    assert pk[0, 0, 0] == 2 and 10.5 < pk[0, 1, 0] < 11.5
+
+
+def test_pair_scores_vector_equals_scalar_and_rules():
+    rng = np.random.default_rng(3)
+    mx = rng.normal(0, 0.5, (64, 96)).astype(np.float32)
+    my = rng.normal(0, 0.5, (64, 96)).astype(np.float32)
+    mx[:, :] += 0.8                                            # mostly aligned with +x
+    a = np.array([[5.5, 10.5, .9], [20.5, 30.5, .8], [50.5, 5.5, .7], [50.5, 5.5, .7]], np.float32)
+    b = np.array([[80.5, 12.5, .9], [22.0, 31.0, .8], [50.5, 5.5, .6]], np.float32)
+    v = decode_v2.pair_scores(a, b, mx, my, 0.05, 0.95, 0.05)
+    for i in range(len(a)):
+        for j in range(len(b)):
+            s = decode_v2.score_ab(a[i], b[j], mx, my, 0.05, 0.95, 0.05)
+            assert s.view(np.uint32) == v[i, j].view(np.uint32)
+    assert v[2, 2] == 0 and v[3, 2] == 0                       # coincident peaks never connect
+    # close-keypoint rescue: distance < sqrt(W*H)/150 scores nms_threshold + 1e-6
+    z = np.zeros((368, 656), np.float32)
+    s = decode_v2.score_ab(np.float32([10, 10, 1]), np.float32([12, 10, 1]), z, z, 0.05, 0.95, 0.05)
+    assert s == np.float32(0.05 + 1e-6)
+    s = decode_v2.score_ab(np.float32([10, 10, 1]), np.float32([20, 10, 1]), z, z, 0.05, 0.95, 0.05)
+    assert s == 0
+
+
+def test_sorted_greedy_and_assembly_rules():
+    model = BODY_25
+    P1 = model.max_peaks + 1
+    peaks = np.zeros((25, P1, 3), np.float32)
+    # limb 0 = (1, 8): two necks, two mid-hips; PAF favours neck0-hip1 and neck1-hip1 -> conflict on hip1
+    peaks[1, 0, 0] = 2
+    peaks[1, 1] = (100, 100, .9)
+    peaks[1, 2] = (300, 100, .8)
+    peaks[8, 0, 0] = 2
+    peaks[8, 1] = (100, 200, .7)
+    peaks[8, 2] = (200, 200, .6)
+    H, W = 368, 656
+    maps = np.zeros((78, H, W), np.float32)
+    ch = model.n_heat + model.mapidx[0][0]
+    maps[ch + 1] = 1.0                                         # PAF points straight down (+y)
+    conns = decode_v2.select_connections(peaks, maps, model, 0)
+    off = 3 * P1
+    # scores: neck0-hip0 = 1 (vertical), neck0-hip1 = cos(45deg), neck1-hip1 = cos(45deg), neck1-hip0 lower
+    assert [(c[0], c[1]) for c in conns] == [(1 * off + 1 * 3 + 2, 8 * off + 1 * 3 + 2),
+                                             (1 * off + 2 * 3 + 2, 8 * off + 2 * 3 + 2)]
+    all_conns = [[] for _ in range(model.n_pairs)]
+    all_conns[0] = conns
+    rows, scores = decode_v2.assemble(peaks, all_conns, model)
+    assert rows.shape == (2, 26) and (rows[:, -1] == 2).all()
+    assert scores[0] == np.float32(np.float32(np.float32(.9) + np.float32(.7)) + conns[0][2])
+    valid = decode_v2.filter_people(rows, scores, model)
+    assert valid == []              # 2 parts < minSubsetCnt (3), also on the maximizePositives retry
+    kp, sc = decode_v2.people_array(rows, scores, [0, 1], peaks, model, 2.0)
+    assert kp.shape == (2, 25, 3) and tuple(kp[0, 1]) == (200.0, 200.0, np.float32(.9)) and (kp[0, 0] == 0).all()
+
+
+def test_filter_rules():
+    model = BODY_25
+    rows = np.zeros((3, 26), np.int32)
+    rows[0, [1, 8, 9]] = 5
+    rows[0, -1] = 3                                            # 3 body parts, good score -> kept
+    rows[1, [1, 8, 19, 20]] = 5
+    rows[1, -1] = 4                                            # 2 body + 2 foot parts -> counter 2 -> dropped
+    rows[2, [1, 8, 9]] = 5
+    rows[2, -1] = 3                                            # low mean score -> dropped
+    scores = np.float32([3 * 0.5, 4 * 0.9, 3 * 0.3])
+    assert decode_v2.filter_people(rows, scores, model) == [0]
+    # nobody passes -> retry without the foot rule
+    assert decode_v2.filter_people(rows[1:2], scores[1:2], model) == [0]
+
+
+def test_reference_predictions_file_format():
+    """The only stored output of the reference's native path pins the FORMAT of
+    (poseScore, 25 x (x, y, score)) rows (native/python/skeleton.py:186-199) and
+    the score convention (sum of part + limb scores) / (25 + 26)."""
+    row = np.loadtxt(os.path.join(G, "ref_predictions_native.txt"), delimiter=",").reshape(1, -1)
+    assert row.shape == (1, 76)
+    score, kp = row[0, 0], row[0, 1:].reshape(25, 3)
+    assert (kp[18] == 0).all() and (kp[np.arange(25) != 18, 2] > 0.05).all()   # undetected joint = zero triplet
+    assert (kp[:, 0] <= 384).all() and (kp[:, 1] <= 384).all()                  # 384x384 frame (test.py:35)
+    limb_sum = score * (BODY_25.n_parts + BODY_25.n_pairs) - kp[:, 2].sum()
+    present = [k for k, (a, b) in enumerate(BODY_25.pairs) if kp[a, 2] > 0 and kp[b, 2] > 0]
+    assert len(present) == 24                                                   # both LEar limbs missing
+    assert 0.05 < limb_sum / len(present) <= 1.0                                # mean limb score is a PAF score
+    # our packer writes the same layout
+    rows = np.zeros((1, 26), np.int32)
+    assert decode_v2.people_array(rows, np.float32([1.0]), [0], np.zeros((25, 128, 3), np.float32),
+                                  BODY_25)[0].shape == (1, 25, 3)
+
+
+@pytest.mark.parametrize("tag,model", [("b25_p3", BODY_25), ("b25_p0", BODY_25), ("b25_sq_p2", BODY_25),
+                                       ("coco_p4", COCO_18)])
+def test_golden_scenes(tag, model):
+    g = np.load(os.path.join(G, "v2_scenes.npz"))
+    net = g[tag + "_net"].astype(np.float32)
+    kp, sc, inter = decode_v2.decode(net, model, net.shape[1] * 8, net.shape[2] * 8, 1.0, return_intermediates=True)
+    np.testing.assert_array_equal(kp, g[tag + "_kp"])
+    np.testing.assert_array_equal(sc, g[tag + "_sc"])
+    np.testing.assert_array_equal(inter["peaks"][:, 0, 0].astype(np.int32), g[tag + "_peaks_n"])
