@@ -144,7 +144,7 @@ static void free_net(ph_ctx* c) {
 }
 
 static void free_v2(ph_ctx* c) {
-  void* ptrs[] = {c->v2.peaks,    c->v2.pair_scores, c->v2.conn_idx, c->v2.conn_score, c->v2.n_conn,
+  void* ptrs[] = {c->v2.nms_keys, c->v2.nms_cnt, c->v2.peaks,    c->v2.pair_scores, c->v2.conn_idx, c->v2.conn_score, c->v2.n_conn,
                   c->v2.n_people, c->v2.keypoints,   c->v2.scores,   c->v2.subsets,    c->v2.overflow};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -609,6 +609,8 @@ static int v2_prepare(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, in
     PH_CHECK(hipStreamSynchronize(c->stream));
     free_v2(c);
     ph_v2_workspace_sizes(*dev, B, max_people, &c->v2sz);
+    PH_CHECK(hipMalloc(&c->v2.nms_keys, c->v2sz.nms_keys));
+    PH_CHECK(hipMalloc(&c->v2.nms_cnt, c->v2sz.nms_cnt));
     PH_CHECK(hipMalloc(&c->v2.peaks, c->v2sz.peaks));
     PH_CHECK(hipMalloc(&c->v2.pair_scores, c->v2sz.pair_scores));
     PH_CHECK(hipMalloc(&c->v2.conn_idx, c->v2sz.conn_idx));

@@ -73,6 +73,12 @@ __device__ __forceinline__ float resize_at(const float* src, int hs, int ws, int
   return r0 * cy.a0 + r1 * cy.a1;
 }
 
+__device__ __forceinline__ float resize_tab(const float* src, int ws, const LinX& cx, const LinX& cy) {
+  const float r0 = src[cy.s0 * ws + cx.s0] * cx.a0 + src[cy.s0 * ws + cx.s1] * cx.a1;
+  const float r1 = src[cy.s1 * ws + cx.s0] * cx.a0 + src[cy.s1 * ws + cx.s1] * cx.a1;
+  return r0 * cy.a0 + r1 * cy.a1;
+}
+
 // ---------------------------------------------------------------------------
 // K-A: mask runs.  grid (tiles_x * tiles_y, n_parts, B), block 256
 // ---------------------------------------------------------------------------
@@ -90,6 +96,8 @@ __global__ __launch_bounds__(256) void v1_runs_kernel(const float* __restrict__ 
   float* s_t = s_heat + (V1_TILE_H + 2) * (V1_TILE_W + 2);  // (TILE_H+2) * TILE_W
   float* s_sm = s_t + (V1_TILE_H + 2) * V1_TILE_W;          // TILE_H * TILE_W
   __shared__ float s_max[4];
+  __shared__ LinX s_lx[V1_TILE_W + 2];   // per-tile coordinate tables: the fp64 coordinate
+  __shared__ LinX s_ly[V1_TILE_H + 2];   // arithmetic runs once per column/row, not per pixel
 
   const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
   // source cells that can reach this tile (1-px blur halo, both bilinear taps)
@@ -113,10 +121,13 @@ __global__ __launch_bounds__(256) void v1_runs_kernel(const float* __restrict__ 
 
   // 1. bilinear-resized heat map, tile + 1-px halo, reflect-101 at the image border
   constexpr int HW_ = V1_TILE_W + 2;
+  for (int c = tid; c < HW_; c += 256)
+    if (x0 - 1 + c <= W) s_lx[c] = lin_x(reflect101(x0 - 1 + c, W), W, ws);
+  if (tid < V1_TILE_H + 2 && y0 - 1 + tid <= H) s_ly[tid] = lin_y(reflect101(y0 - 1 + tid, H), H, hs);
+  __syncthreads();
   for (int i = tid; i < (V1_TILE_H + 2) * HW_; i += 256) {
     const int r = i / HW_, c = i - r * HW_;
-    const int y = reflect101(y0 - 1 + r, H), x = reflect101(x0 - 1 + c, W);
-    s_heat[i] = (y0 - 1 + r <= H && x0 - 1 + c <= W) ? resize_at(s_src, hs, ws, W, H, x, y) : 0.f;
+    s_heat[i] = (y0 - 1 + r <= H && x0 - 1 + c <= W) ? resize_tab(s_src, ws, s_lx[c], s_ly[r]) : 0.f;
   }
   __syncthreads();
   // 2. row pass  c*1/2 + (l + r)*1/4
@@ -503,7 +514,7 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   const size_t ldsB = ((size_t)2 * c.run_cap + H + 2 + c.kp_cap) * 4;
   const size_t ldsC = (size_t)2 * hs * ws * 4;
   const size_t ldsD = (size_t)c.person_cap * (m.n_parts + 1) * 8;
-  const size_t lim = 160 * 1024 - 2048;
+  const size_t lim = 160 * 1024 - 8192;  // static __shared__ tables sit beside the dynamic region
   if (ldsA > lim || ldsB > lim || ldsC > lim || ldsD > lim) {
     ph_set_error("decode_v1: LDS budget exceeded (%zu/%zu/%zu/%zu B)", ldsA, ldsB, ldsC, ldsD);
     return -1;

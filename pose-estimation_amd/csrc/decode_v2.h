@@ -13,11 +13,15 @@ struct PhV2Dev {
   int mapidx[128];
 };
 
+#define PH_V2_NMS_SPLIT 4  // horizontal stripes per heat map in the NMS kernel
+
 struct PhV2Sizes {
-  size_t peaks, pair_scores, conn_idx, conn_score, n_conn, n_people, keypoints, scores, subsets;
+  size_t nms_keys, nms_cnt, peaks, pair_scores, conn_idx, conn_score, n_conn, n_people, keypoints, scores, subsets;
 };
 
 struct PhV2Buffers {
+  int* nms_keys;
+  int* nms_cnt;
   float* peaks;
   float* pair_scores;
   int* conn_idx;

@@ -45,86 +45,114 @@ __device__ __forceinline__ Taps src_taps(int x, int n_target, int n_source) {
   return t;
 }
 
+// packed taps kept in LDS tables (one fp32 division per output column/row per block
+// instead of one per pixel)
+struct __attribute__((aligned(4))) TapsP {
+  unsigned short i0, i1, i2, i3;
+  float d;
+};
+__device__ __forceinline__ TapsP pack_taps(const Taps& t) {
+  TapsP p;
+  p.i0 = (unsigned short)t.i0;
+  p.i1 = (unsigned short)t.i1;
+  p.i2 = (unsigned short)t.i2;
+  p.i3 = (unsigned short)t.i3;
+  p.d = t.d;
+  return p;
+}
+
+__device__ __forceinline__ float cubic_row(const float* r, const TapsP& tx) {
+  return cubic(r[tx.i0], r[tx.i1], r[tx.i2], r[tx.i3], tx.d);
+}
+__device__ __forceinline__ float bicubic_tp(const float* src, int ws, const TapsP& tx, const TapsP& ty) {
+  const float t0 = cubic_row(src + ty.i0 * ws, tx), t1 = cubic_row(src + ty.i1 * ws, tx);
+  const float t2 = cubic_row(src + ty.i2 * ws, tx), t3 = cubic_row(src + ty.i3 * ws, tx);
+  return cubic(t0, t1, t2, t3, ty.d);
+}
+
 // one pixel of the upsampled map from a source plane (LDS or global)
 __device__ __forceinline__ float bicubic_at(const float* src, int hs, int ws, int Ht, int Wt, int x, int y) {
-  const Taps tx = src_taps(x, Wt, ws);
-  const Taps ty = src_taps(y, Ht, hs);
-  const int rows[4] = {ty.i0, ty.i1, ty.i2, ty.i3};
-  float t[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float* r = src + rows[i] * ws;
-    t[i] = cubic(r[tx.i0], r[tx.i1], r[tx.i2], r[tx.i3], tx.d);
-  }
-  return cubic(t[0], t[1], t[2], t[3], ty.d);
+  const TapsP tx = pack_taps(src_taps(x, Wt, ws)), ty = pack_taps(src_taps(y, Ht, hs));
+  return bicubic_tp(src, ws, tx, ty);
 }
 
 // ---------------------------------------------------------------------------
-// kernel 1: fused bicubic upsample + NMS + ordered compaction + refine
-// grid (n_parts, B), block 256
+// kernel 1a: fused bicubic upsample + strict 3x3 NMS + ordered compaction.
+// grid (n_parts, B, n_split): each block owns a horizontal stripe of the
+// upsampled map and emits that stripe's peak pixels in raster order.
 // ---------------------------------------------------------------------------
 #define NMS_BAND 8
-#define NMS_TROWS 7  // source rows touched by NMS_BAND+2 output rows at scale >= 4: 3 steps + 4 taps
+#define NMS_TRING 8  // source rows live at once: (NMS_BAND + 2) / scale + 4 taps <= 7 for scale >= 4
 
-__global__ __launch_bounds__(256) void upsample_nms_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
-                                                           int Ht, int Wt, float threshold, int max_peaks,
-                                                           float* __restrict__ peaks, int n_parts) {
+__global__ __launch_bounds__(256) void nms_detect_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
+                                                         int Ht, int Wt, float threshold, int max_peaks, int n_parts,
+                                                         int n_split, int rows_per_split, int* __restrict__ keys,
+                                                         int* __restrict__ key_cnt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  float* s_src = smem;                                  // hs*ws
-  float* s_T = s_src + hs * ws;                         // NMS_TROWS * Wt
-  float* s_U = s_T + NMS_TROWS * Wt;                    // (NMS_BAND+2) * Wt
-  int* s_cand = (int*)(s_U + (NMS_BAND + 2) * Wt);      // (NMS_BAND/2) * (Wt/2+1)
-  int* s_keys = s_cand + (NMS_BAND / 2) * (Wt / 2 + 1); // max_peaks
+  const int part = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
+  float* s_src = smem;                                   // hs*ws
+  float* s_T = s_src + hs * ws;                          // NMS_TRING * Wt : source row r at slot r & 7
+  float* s_U = s_T + NMS_TRING * Wt;                     // (NMS_BAND+2) * Wt
+  TapsP* s_xt = (TapsP*)(s_U + (NMS_BAND + 2) * Wt);     // Wt
+  int* s_cand = (int*)(s_xt + Wt);                       // (NMS_BAND/2) * (Wt/2+1)
+  int* s_keys = s_cand + (NMS_BAND / 2) * (Wt / 2 + 1);  // max_peaks
+  __shared__ TapsP s_yt[NMS_BAND + 2];
   __shared__ int s_ncand;
 
   const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
   for (int i = tid; i < hs * ws; i += 256) s_src[i] = plane[i];
+  for (int x = tid; x < Wt; x += 256) s_xt[x] = pack_taps(src_taps(x, Wt, ws));
   if (tid == 0) s_ncand = 0;
   __syncthreads();
 
-  int base = 0;  // peaks found so far (uniform across the block)
-  for (int r0 = 0; r0 < Ht && base < max_peaks; r0 += NMS_BAND) {
+  const int y_begin = sp * rows_per_split;
+  const int y_end = y_begin + rows_per_split < Ht ? y_begin + rows_per_split : Ht;
+  int base = 0;      // peaks found so far in this stripe (uniform across the block)
+  int t_done = -1;   // highest source row already in the T ring
+  for (int r0 = y_begin; r0 < y_end && base < max_peaks; r0 += NMS_BAND) {
     // output rows needed: [r0-1, r0+NMS_BAND] clamped to the image
     const int ylo = r0 - 1 < 0 ? 0 : r0 - 1;
     const int yhi = r0 + NMS_BAND > Ht - 1 ? Ht - 1 : r0 + NMS_BAND;
+    const int nrows_u = yhi - ylo + 1;
+    if (tid < nrows_u) s_yt[tid] = pack_taps(src_taps(ylo + tid, Ht, hs));
     const int slo = src_taps(ylo, Ht, hs).i0;
     const int shi = src_taps(yhi, Ht, hs).i3;
-    const int nrows_t = shi - slo + 1;  // <= NMS_TROWS (checked on host)
-    // 1. horizontal cubic of the touched source rows
-    for (int i = tid; i < nrows_t * Wt; i += 256) {
-      const int rr = i / Wt, x = i - rr * Wt;
-      const Taps tx = src_taps(x, Wt, ws);
-      const float* r = s_src + (slo + rr) * ws;
-      s_T[rr * Wt + x] = cubic(r[tx.i0], r[tx.i1], r[tx.i2], r[tx.i3], tx.d);
+    // 1. horizontal cubic of the source rows not yet in the ring
+    const int t_first = t_done + 1 > slo ? t_done + 1 : slo;
+    for (int x = tid; x < Wt; x += 256) {
+      const TapsP tx = s_xt[x];
+      for (int sr = t_first; sr <= shi; sr++)
+        s_T[(sr & (NMS_TRING - 1)) * Wt + x] = cubic_row(s_src + sr * ws, tx);
     }
+    t_done = shi;
     __syncthreads();
     // 2. vertical cubic -> upsampled band with a 1-row halo
-    const int nrows_u = yhi - ylo + 1;
-    for (int i = tid; i < nrows_u * Wt; i += 256) {
-      const int rr = i / Wt, x = i - rr * Wt;
-      const Taps ty = src_taps(ylo + rr, Ht, hs);
-      s_U[rr * Wt + x] = cubic(s_T[(ty.i0 - slo) * Wt + x], s_T[(ty.i1 - slo) * Wt + x],
-                               s_T[(ty.i2 - slo) * Wt + x], s_T[(ty.i3 - slo) * Wt + x], ty.d);
-    }
+    for (int x = tid; x < Wt; x += 256)
+      for (int rr = 0; rr < nrows_u; rr++) {
+        const TapsP ty = s_yt[rr];
+        s_U[rr * Wt + x] =
+            cubic(s_T[(ty.i0 & (NMS_TRING - 1)) * Wt + x], s_T[(ty.i1 & (NMS_TRING - 1)) * Wt + x],
+                  s_T[(ty.i2 & (NMS_TRING - 1)) * Wt + x], s_T[(ty.i3 & (NMS_TRING - 1)) * Wt + x], ty.d);
+      }
     __syncthreads();
     // 3. strict 3x3 maxima above threshold, 1-px image border excluded
     const int y_first = r0 < 1 ? 1 : r0;
-    const int y_last = r0 + NMS_BAND - 1 > Ht - 2 ? Ht - 2 : r0 + NMS_BAND - 1;
-    const int nrows_d = y_last - y_first + 1;
-    for (int i = tid; i < nrows_d * (Wt - 2); i += 256) {
-      const int rr = i / (Wt - 2), x = i - rr * (Wt - 2) + 1;
-      const int y = y_first + rr;
-      const float* u = s_U + (y - ylo) * Wt + x;
-      const float v = u[0];
-      if (v > threshold && v > u[-Wt - 1] && v > u[-Wt] && v > u[-Wt + 1] && v > u[-1] && v > u[1] &&
-          v > u[Wt - 1] && v > u[Wt] && v > u[Wt + 1]) {
-        const int slot = atomicAdd(&s_ncand, 1);
-        s_cand[slot] = y * Wt + x;
+    int y_last = r0 + NMS_BAND - 1 > Ht - 2 ? Ht - 2 : r0 + NMS_BAND - 1;
+    y_last = y_last > y_end - 1 ? y_end - 1 : y_last;
+    for (int x = tid + 1; x < Wt - 1; x += 256)
+      for (int y = y_first; y <= y_last; y++) {
+        const float* u = s_U + (y - ylo) * Wt + x;
+        const float v = u[0];
+        if (v > threshold) {
+          if (v > u[-Wt - 1] && v > u[-Wt] && v > u[-Wt + 1] && v > u[-1] && v > u[1] && v > u[Wt - 1] &&
+              v > u[Wt] && v > u[Wt + 1]) {
+            const int slot = atomicAdd(&s_ncand, 1);
+            s_cand[slot] = y * Wt + x;
+          }
+        }
       }
-    }
     __syncthreads();
-    // 4. raster order inside the band by rank; keep the first max_peaks overall
+    // 4. raster order inside the band by rank; keep the first max_peaks of the stripe
     const int n = s_ncand;
     for (int i = tid; i < n; i += 256) {
       const int key = s_cand[i];
@@ -137,30 +165,68 @@ __global__ __launch_bounds__(256) void upsample_nms_kernel(const float* __restri
     if (tid == 0) s_ncand = 0;
     __syncthreads();
   }
-
   const int count = base < max_peaks ? base : max_peaks;
+  int* out = keys + (((size_t)b * n_parts + part) * n_split + sp) * max_peaks;
+  for (int k = tid; k < count; k += 256) out[k] = s_keys[k];
+  if (tid == 0) key_cnt[((size_t)b * n_parts + part) * n_split + sp] = count;
+}
+
+// ---------------------------------------------------------------------------
+// kernel 1b: concatenate the stripes' peak lists (raster order, first
+// max_peaks), 7x7 score-weighted centroid.  grid (n_parts, B), block 128
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void nms_refine_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
+                                                         int Ht, int Wt, int max_peaks, int n_parts, int n_split,
+                                                         const int* __restrict__ keys,
+                                                         const int* __restrict__ key_cnt, float* __restrict__ peaks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  float* s_src = smem;
+  const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
+  const int* cnt = key_cnt + ((size_t)b * n_parts + part) * n_split;
+  int total = 0;
+  for (int s = 0; s < n_split; s++) total += cnt[s];
+  const int count = total < max_peaks ? total : max_peaks;
   float* out = peaks + ((size_t)b * n_parts + part) * (max_peaks + 1) * 3;
   if (tid == 0) out[0] = (float)count;
-  // 5. 7x7 score-weighted centroid, sequential fp32 sums in (y, x) order
-  for (int k = tid; k < count; k += 256) {
-    const int key = s_keys[k];
+  if (count == 0) return;
+  for (int i = tid; i < hs * ws; i += 128) s_src[i] = plane[i];
+  __syncthreads();
+  for (int k = tid; k < count; k += 128) {
+    int s = 0, kk = k;
+    while (kk >= cnt[s]) {
+      kk -= cnt[s];
+      s++;
+    }
+    const int key = keys[(((size_t)b * n_parts + part) * n_split + s) * max_peaks + kk];
     const int py = key / Wt, px = key - py * Wt;
+    // sequential fp32 sums in (y, x) order over the in-image part of the 7x7 window
+    TapsP tx[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      int xx = px - 3 + i;
+      xx = xx < 0 ? 0 : (xx > Wt - 1 ? Wt - 1 : xx);
+      tx[i] = pack_taps(src_taps(xx, Wt, ws));
+    }
     float xacc = 0.f, yacc = 0.f, sacc = 0.f;
     for (int yy = py - 3; yy <= py + 3; yy++) {
       if (yy < 0 || yy >= Ht) continue;
-      for (int xx = px - 3; xx <= px + 3; xx++) {
+      const TapsP ty = pack_taps(src_taps(yy, Ht, hs));
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        const int xx = px - 3 + i;
         if (xx < 0 || xx >= Wt) continue;
-        const float s = bicubic_at(s_src, hs, ws, Ht, Wt, xx, yy);
-        if (s > 0.f) {
-          xacc = xacc + (float)xx * s;
-          yacc = yacc + (float)yy * s;
-          sacc = sacc + s;
+        const float sv = bicubic_tp(s_src, ws, tx[i], ty);
+        if (sv > 0.f) {
+          xacc = xacc + (float)xx * sv;
+          yacc = yacc + (float)yy * sv;
+          sacc = sacc + sv;
         }
       }
     }
-    out[(k + 1) * 3 + 0] = ((xacc) / (sacc)) + 0.5f;
-    out[(k + 1) * 3 + 1] = ((yacc) / (sacc)) + 0.5f;
-    out[(k + 1) * 3 + 2] = bicubic_at(s_src, hs, ws, Ht, Wt, px, py);
+    out[(k + 1) * 3 + 0] = xacc / sacc + 0.5f;
+    out[(k + 1) * 3 + 1] = yacc / sacc + 0.5f;
+    out[(k + 1) * 3 + 2] = bicubic_tp(s_src, ws, tx[3], pack_taps(src_taps(py, Ht, hs)));
   }
 }
 
@@ -170,9 +236,11 @@ __global__ __launch_bounds__(256) void upsample_nms_kernel(const float* __restri
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int pir(float x) { return (int)(x + 0.5f); }
 
-__device__ float score_ab(const float* A, const float* Bp, const float* mapx, const float* mapy, int hs, int ws,
-                          int Ht, int Wt, float inter_thr, float inter_min_above, double close_thr,
-                          float close_score) {
+#define PAF_LIST_CAP 2048
+
+__device__ float score_ab(const float* A, const float* Bp, const float* mapx, const float* mapy, int ws, int Ht,
+                          int Wt, const TapsP* xt, const TapsP* yt, float inter_thr, float inter_min_above,
+                          double close_thr, float close_score) {
   const float vx = Bp[0] - A[0];
   const float vy = Bp[1] - A[1];
   const float vmax = fmaxf(fabsf(vx), fabsf(vy));
@@ -182,26 +250,34 @@ __device__ float score_ab(const float* A, const float* Bp, const float* mapx, co
   const float norm = sqrtf(vx * vx + vy * vy);
   if ((double)norm > 1e-6) {
     const float sx = A[0], sy = A[1];
-    const float nx = ((vx) / (norm)), ny = ((vy) / (norm));
+    const float nx = vx / norm, ny = vy / norm;
     float total = 0.f;
     int count = 0;
-    const float stepx = vx / (float)npts, stepy = vy / (float)npts;
+    const float fn = (float)npts;
+    const float stepx = vx / fn, stepy = vy / fn;
+    bool alive = true;
     for (int lm = 0; lm < npts; lm++) {
+      // the acceptance test below can no longer pass: the sum is not needed (same result, less work)
+      if (!((float)(count + npts - lm) / fn > inter_min_above)) {
+        alive = false;
+        break;
+      }
       int mx = pir(sx + (float)lm * stepx);
       int my = pir(sy + (float)lm * stepy);
       mx = mx > Wt - 1 ? Wt - 1 : mx;
       mx = mx < 0 ? 0 : mx;
       my = my > Ht - 1 ? Ht - 1 : my;
       my = my < 0 ? 0 : my;
-      const float px = bicubic_at(mapx, hs, ws, Ht, Wt, mx, my);
-      const float py = bicubic_at(mapy, hs, ws, Ht, Wt, mx, my);
+      const TapsP tx = xt[mx], ty = yt[my];
+      const float px = bicubic_tp(mapx, ws, tx, ty);
+      const float py = bicubic_tp(mapy, ws, tx, ty);
       const float s = nx * px + ny * py;
       if (s > inter_thr) {
         total = total + s;
         count++;
       }
     }
-    if ((float)count / (float)npts > inter_min_above) return total / (float)count;
+    if (alive && (float)count / fn > inter_min_above) return total / (float)count;
     if ((double)norm < close_thr) return close_score;
   }
   return 0.f;
@@ -224,14 +300,17 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
     if (tid == 0) *out_n = 0;
     return;
   }
-  float* s_mx = smem;
+  unsigned long long* s_list = (unsigned long long*)smem;  // PAF_LIST_CAP accepted (score, i, j) keys
+  float* s_mx = (float*)(s_list + PAF_LIST_CAP);
   float* s_my = s_mx + hs * ws;
   float* s_A = s_my + hs * ws;  // P1*3
   float* s_B = s_A + P1 * 3;
-  unsigned char* s_occA = (unsigned char*)(s_B + P1 * 3);
+  TapsP* s_xt = (TapsP*)(s_B + P1 * 3);  // Wt
+  TapsP* s_yt = s_xt + Wt;               // Ht
+  unsigned char* s_occA = (unsigned char*)(s_yt + Ht);
   unsigned char* s_occB = s_occA + P1;
   __shared__ unsigned long long s_best;
-  __shared__ int s_count;
+  __shared__ int s_count, s_nlist;
 
   const float* px = net_out + ((size_t)b * C + mdl.n_heat + mdl.mapidx[2 * pair]) * hs * ws;
   const float* py = net_out + ((size_t)b * C + mdl.n_heat + mdl.mapidx[2 * pair + 1]) * hs * ws;
@@ -247,9 +326,12 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
     s_occA[i] = 0;
     s_occB[i] = 0;
   }
+  for (int x = tid; x < Wt; x += 256) s_xt[x] = pack_taps(src_taps(x, Wt, ws));
+  for (int y = tid; y < Ht; y += 256) s_yt[y] = pack_taps(src_taps(y, Ht, hs));
   if (tid == 0) {
     s_best = 0ull;
     s_count = 0;
+    s_nlist = 0;
   }
   __syncthreads();
 
@@ -257,26 +339,42 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
   const int npairs = nA * nB;
   for (int p = tid; p < npairs; p += 256) {
     const int i = p / nB, j = p - i * nB;  // 0-based
-    sc[p] = score_ab(s_A + (i + 1) * 3, s_B + (j + 1) * 3, s_mx, s_my, hs, ws, Ht, Wt, mdl.inter_threshold,
-                     mdl.inter_min_above, mdl.close_thr, mdl.close_score);
+    const float s = score_ab(s_A + (i + 1) * 3, s_B + (j + 1) * 3, s_mx, s_my, ws, Ht, Wt, s_xt, s_yt,
+                             mdl.inter_threshold, mdl.inter_min_above, mdl.close_thr, mdl.close_score);
+    sc[p] = s;
+    if ((double)s > 1e-6) {
+      const int slot = atomicAdd(&s_nlist, 1);
+      if (slot < PAF_LIST_CAP)
+        s_list[slot] = ((unsigned long long)__float_as_uint(s) << 32) | ((unsigned)(i + 1) << 16) | (unsigned)(j + 1);
+    }
   }
-  __syncthreads();  // this block's own global writes are visible to it after the barrier's vmcnt(0)
+  __syncthreads();  // list complete; this block's own global writes are visible to it
 
   // sorted-greedy == repeatedly take the max (score, i, j) with both ends free
   const int minAB = nA < nB ? nA : nB;
+  const int nlist = s_nlist;
+  const bool use_list = nlist <= PAF_LIST_CAP;
   int* oi = conn_idx + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * 2;
   float* os = conn_score + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks;
   const int off = 3 * P1;
-  for (int it = 0; it < minAB; it++) {
+  for (int it = 0; it < minAB && nlist > 0; it++) {
     unsigned long long best = 0ull;
-    for (int p = tid; p < npairs; p += 256) {
-      const float s = sc[p];
-      if ((double)s > 1e-6) {
-        const int i = p / nB, j = p - i * nB;
-        if (!s_occA[i] && !s_occB[j]) {
-          const unsigned long long key =
-              ((unsigned long long)__float_as_uint(s) << 32) | ((unsigned)(i + 1) << 16) | (unsigned)(j + 1);
-          best = key > best ? key : best;
+    if (use_list) {
+      for (int q = tid; q < nlist; q += 256) {
+        const unsigned long long key = s_list[q];
+        const int i = (int)((key >> 16) & 0xffff) - 1, j = (int)(key & 0xffff) - 1;
+        if (!s_occA[i] && !s_occB[j]) best = key > best ? key : best;
+      }
+    } else {
+      for (int p = tid; p < npairs; p += 256) {
+        const float s = sc[p];
+        if ((double)s > 1e-6) {
+          const int i = p / nB, j = p - i * nB;
+          if (!s_occA[i] && !s_occB[j]) {
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(s) << 32) | ((unsigned)(i + 1) << 16) | (unsigned)(j + 1);
+            best = key > best ? key : best;
+          }
         }
       }
     }
@@ -303,6 +401,8 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------
 // kernel 3: person assembly + filter + pack.  grid (B), block 64 (one wave)
+// The serial part touches LDS only: peak scores, the current limb's
+// connection list and the person table are staged there.
 // ---------------------------------------------------------------------------
 #define ASM_MAX_PARTS 32
 
@@ -317,12 +417,23 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
   const int b = blockIdx.x, lane = threadIdx.x;
   const int NP = mdl.n_parts, P1 = mdl.max_peaks + 1, off = 3 * P1;
   const int RW = NP + 1;  // uint16 words per row (last = part count)
-  float* s_score = smem;                                    // row_cap
-  unsigned short* s_rows = (unsigned short*)(s_score + row_cap);  // row_cap * RW
+  float* s_score = smem;                          // row_cap
+  float* s_pk = s_score + row_cap;                // NP * P1 peak scores ([part][0] = count)
+  float* s_cs = s_pk + NP * P1;                   // max_peaks connection scores
+  int* s_ci = (int*)(s_cs + mdl.max_peaks);       // 2 * max_peaks
+  unsigned short* s_rows = (unsigned short*)(s_ci + 2 * mdl.max_peaks);  // row_cap * RW
   __shared__ int s_nrows;
+  __shared__ int s_nc[64];
   const float* pk = peaks + (size_t)b * NP * off;
+  for (int i = lane; i < NP * P1; i += 64) {
+    const int part = i / P1, k = i - part * P1;
+    s_pk[i] = k == 0 ? pk[part * off] : pk[part * off + k * 3 + 2];
+  }
+  for (int i = lane; i < mdl.n_pairs; i += 64) s_nc[i] = n_conn[(size_t)b * mdl.n_pairs + i];
   if (lane == 0) s_nrows = 0;
   __syncthreads();
+  // score of the peak with upstream index idx = part*off + i*3 + 2
+  auto pscore = [&](int idx) -> float { return s_pk[(idx / off) * P1 + (idx % off) / 3]; };
 
   auto add_row = [&](int pa, int ia, int pb, int ib, int cnt, float sc) {  // lane 0 only
     const int r = s_nrows;
@@ -352,32 +463,35 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
 
   for (int pair = 0; pair < mdl.n_pairs; pair++) {
     const int partA = mdl.pairs[2 * pair], partB = mdl.pairs[2 * pair + 1];
-    const int nA = pir(pk[partA * off]), nB = pir(pk[partB * off]);
+    const int nA = pir(s_pk[partA * P1]), nB = pir(s_pk[partB * P1]);
     if (nA == 0 || nB == 0) {
       const int part = nA == 0 ? partB : partA;
       const int n = nA == 0 ? nB : nA;
       for (int i = 1; i <= n; i++) {
         const int idx = part * off + i * 3 + 2;
         const int f = find_row(part, idx);
-        if (f < 0 && lane == 0) add_row(part, idx, -1, 0, 1, pk[idx]);
+        if (f < 0 && lane == 0) add_row(part, idx, -1, 0, 1, s_pk[part * P1 + i]);
         __syncthreads();
       }
       continue;
     }
-    const int nc = n_conn[(size_t)b * mdl.n_pairs + pair];
-    const int* ci = conn_idx + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * 2;
-    const float* cs = conn_score + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks;
+    const int nc = s_nc[pair];
     if (nc == 0) continue;
+    const int* gci = conn_idx + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * 2;
+    const float* gcs = conn_score + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks;
+    for (int i = lane; i < 2 * nc; i += 64) s_ci[i] = gci[i];
+    for (int i = lane; i < nc; i += 64) s_cs[i] = gcs[i];
+    __syncthreads();
     if (pair == 0) {
       if (lane == 0)
         for (int c = 0; c < nc; c++) {
-          const int ia = ci[2 * c], ib = ci[2 * c + 1];
-          add_row(partA, ia, partB, ib, 2, (pk[ia] + pk[ib]) + cs[c]);
+          const int ia = s_ci[2 * c], ib = s_ci[2 * c + 1];
+          add_row(partA, ia, partB, ib, 2, (pscore(ia) + pscore(ib)) + s_cs[c]);
         }
       __syncthreads();
     } else if (pair == mdl.ear_pair0 || pair == mdl.ear_pair1) {
       for (int c = 0; c < nc; c++) {
-        const int ia = ci[2 * c], ib = ci[2 * c + 1];
+        const int ia = s_ci[2 * c], ib = s_ci[2 * c + 1];
         const int n = s_nrows;
         for (int r = lane; r < n; r += 64) {
           unsigned short* row = s_rows + r * RW;
@@ -390,22 +504,23 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
       }
     } else {
       for (int c = 0; c < nc; c++) {
-        const int ia = ci[2 * c], ib = ci[2 * c + 1];
-        const float s = cs[c];
+        const int ia = s_ci[2 * c], ib = s_ci[2 * c + 1];
+        const float s = s_cs[c];
         const int f = find_row(partA, ia);
         if (lane == 0) {
           if (f >= 0) {
             unsigned short* row = s_rows + f * RW;
             row[partB] = (unsigned short)ib;
             row[NP] = row[NP] + 1;
-            s_score[f] = s_score[f] + (pk[ib] + s);
+            s_score[f] = s_score[f] + (pscore(ib) + s);
           } else {
-            add_row(partA, ia, partB, ib, 2, (pk[ia] + pk[ib]) + s);
+            add_row(partA, ia, partB, ib, 2, (pscore(ia) + pscore(ib)) + s);
           }
         }
         __syncthreads();
       }
     }
+    __syncthreads();  // s_ci / s_cs are reloaded by the next limb
   }
   __syncthreads();
 
@@ -446,7 +561,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
               kp[k * 3 + 2] = 0.f;
             }
           }
-          scores[(size_t)b * max_people + o] = ((s_score[r]) / (denom));
+          scores[(size_t)b * max_people + o] = s_score[r] / denom;
           if (subsets) {
             int* sb = subsets + ((size_t)b * max_people + o) * RW;
             for (int k = 0; k <= NP; k++) sb[k] = row[k];
@@ -541,6 +656,8 @@ int ph_v2_workspace_sizes(const PhV2Dev& m, int B, int max_people, PhV2Sizes* s)
   s->keypoints = (size_t)B * max_people * m.n_parts * 3 * sizeof(float);
   s->scores = (size_t)B * max_people * sizeof(float);
   s->subsets = (size_t)B * max_people * (m.n_parts + 1) * sizeof(int);
+  s->nms_keys = (size_t)B * m.n_parts * PH_V2_NMS_SPLIT * m.max_peaks * sizeof(int);
+  s->nms_cnt = (size_t)B * m.n_parts * PH_V2_NMS_SPLIT * sizeof(int);
   return 0;
 }
 
@@ -562,24 +679,28 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
     ph_set_error("decode_v2: net output has %d channels, model needs %d", C, m.n_heat + 2 * m.n_pairs);
     return -1;
   }
-  const size_t lds1 = ((size_t)hs * ws + (size_t)NMS_TROWS * Wt + (size_t)(NMS_BAND + 2) * Wt +
-                       (size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4;
-  const size_t lds2 = ((size_t)2 * hs * ws + (size_t)2 * (m.max_peaks + 1) * 3) * 4 + 2 * (m.max_peaks + 1) + 16;
+  const int n_split = PH_V2_NMS_SPLIT;
+  const int rows_per_split = (((Ht + n_split - 1) / n_split) + NMS_BAND - 1) / NMS_BAND * NMS_BAND;
+  const size_t lds1 = ((size_t)hs * ws + (size_t)NMS_TRING * Wt + (size_t)(NMS_BAND + 2) * Wt) * 4 +
+                      (size_t)Wt * sizeof(TapsP) + ((size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4;
+  const size_t lds1b = (size_t)hs * ws * 4;
+  const size_t lds2 = (size_t)PAF_LIST_CAP * 8 + ((size_t)2 * hs * ws + (size_t)2 * (m.max_peaks + 1) * 3) * 4 +
+                      (size_t)(Wt + Ht) * sizeof(TapsP) + 2 * (m.max_peaks + 1) + 16;
   const int row_cap = 2048;
-  const size_t lds3 = (size_t)row_cap * 4 + (size_t)row_cap * (m.n_parts + 1) * 2;
-  if (lds1 > 160 * 1024 - 64 || lds2 > 160 * 1024 - 64 || lds3 > 160 * 1024 - 64) {
+  const size_t lds3 = ((size_t)row_cap + (size_t)m.n_parts * (m.max_peaks + 1) + 3 * (size_t)m.max_peaks) * 4 +
+                      (size_t)row_cap * (m.n_parts + 1) * 2;
+  const size_t lim = 160 * 1024 - 1024;
+  if (lds1 > lim || lds1b > lim || lds2 > lim || lds3 > lim || hs > 65535 || ws > 65535) {
     ph_set_error("decode_v2: LDS budget exceeded (%zu/%zu/%zu B) for net output %dx%d target %dx%d", lds1, lds2,
                  lds3, hs, ws, Ht, Wt);
     return -1;
   }
   static bool attr_done = false;
   if (!attr_done) {
-    PH_CHECK(hipFuncSetAttribute((const void*)upsample_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 160 * 1024 - 64));
-    PH_CHECK(hipFuncSetAttribute((const void*)paf_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 160 * 1024 - 64));
-    PH_CHECK(hipFuncSetAttribute((const void*)assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 160 * 1024 - 64));
+    PH_CHECK(hipFuncSetAttribute((const void*)nms_detect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
+    PH_CHECK(hipFuncSetAttribute((const void*)nms_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
+    PH_CHECK(hipFuncSetAttribute((const void*)paf_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
+    PH_CHECK(hipFuncSetAttribute((const void*)assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
     attr_done = true;
   }
   PhV2Sizes sz;
@@ -587,8 +708,10 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   PH_CHECK(hipMemsetAsync(w.peaks, 0, sz.peaks, stream));
   PH_CHECK(hipMemsetAsync(w.overflow, 0, sizeof(int), stream));
   if (ev) PH_CHECK(hipEventRecord(ev[0], stream));
-  hipLaunchKernelGGL(upsample_nms_kernel, dim3(m.n_parts, B), dim3(256), lds1, stream, net_out, C, hs, ws, Ht, Wt,
-                     m.nms_threshold, m.max_peaks, w.peaks, m.n_parts);
+  hipLaunchKernelGGL(nms_detect_kernel, dim3(m.n_parts, B, n_split), dim3(256), lds1, stream, net_out, C, hs, ws, Ht,
+                     Wt, m.nms_threshold, m.max_peaks, m.n_parts, n_split, rows_per_split, w.nms_keys, w.nms_cnt);
+  hipLaunchKernelGGL(nms_refine_kernel, dim3(m.n_parts, B), dim3(128), lds1b, stream, net_out, C, hs, ws, Ht, Wt,
+                     m.max_peaks, m.n_parts, n_split, (const int*)w.nms_keys, (const int*)w.nms_cnt, w.peaks);
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(paf_match_kernel, dim3(m.n_pairs, B), dim3(256), lds2, stream, net_out, C, hs, ws, Ht, Wt,
                      (const float*)w.peaks, m, w.pair_scores, w.conn_idx, w.conn_score, w.n_conn);
