@@ -307,7 +307,10 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
   float* s_B = s_A + P1 * 3;
   TapsP* s_xt = (TapsP*)(s_B + P1 * 3);  // Wt
   TapsP* s_yt = s_xt + Wt;               // Ht
-  unsigned char* s_occA = (unsigned char*)(s_yt + Ht);
+  unsigned long long* s_bestA = (unsigned long long*)(s_yt + Ht + ((Wt + Ht) & 1));  // keep 8-byte alignment
+  unsigned long long* s_bestB = s_bestA + P1;
+  unsigned long long* s_sel = s_bestB + P1;  // selected keys, <= min(nA, nB) <= max_peaks
+  unsigned char* s_occA = (unsigned char*)(s_sel + P1);
   unsigned char* s_occB = s_occA + P1;
   __shared__ unsigned long long s_best;
   __shared__ int s_count, s_nlist;
@@ -350,61 +353,93 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
   }
   __syncthreads();  // list complete; this block's own global writes are visible to it
 
-  // sorted-greedy == repeatedly take the max (score, i, j) with both ends free
-  const int minAB = nA < nB ? nA : nB;
+  // Sorted-greedy matching, in parallel.  Upstream sorts all accepted (score, i, j)
+  // descending and takes a pair when both ends are unused.  A pair that is the largest
+  // remaining key of BOTH its endpoints is always taken by that scan, so each round
+  // selects every such pair at once (keys are unique); rounds repeat until nothing is
+  // free.  The selected set equals the sequential result; it is emitted in descending
+  // key order = the order upstream appends connections.
   const int nlist = s_nlist;
   const bool use_list = nlist <= PAF_LIST_CAP;
   int* oi = conn_idx + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * 2;
   float* os = conn_score + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks;
   const int off = 3 * P1;
-  for (int it = 0; it < minAB && nlist > 0; it++) {
-    unsigned long long best = 0ull;
+  auto for_each_free = [&](auto&& fn) {
     if (use_list) {
       for (int q = tid; q < nlist; q += 256) {
         const unsigned long long key = s_list[q];
         const int i = (int)((key >> 16) & 0xffff) - 1, j = (int)(key & 0xffff) - 1;
-        if (!s_occA[i] && !s_occB[j]) best = key > best ? key : best;
+        if (!s_occA[i] && !s_occB[j]) fn(key, i, j);
       }
     } else {
       for (int p = tid; p < npairs; p += 256) {
         const float s = sc[p];
         if ((double)s > 1e-6) {
           const int i = p / nB, j = p - i * nB;
-          if (!s_occA[i] && !s_occB[j]) {
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(s) << 32) | ((unsigned)(i + 1) << 16) | (unsigned)(j + 1);
-            best = key > best ? key : best;
-          }
+          if (!s_occA[i] && !s_occB[j])
+            fn(((unsigned long long)__float_as_uint(s) << 32) | ((unsigned)(i + 1) << 16) | (unsigned)(j + 1), i, j);
         }
       }
     }
-    if (best) atomicMax(&s_best, best);
-    __syncthreads();
-    const unsigned long long win = s_best;
-    __syncthreads();
-    if (win == 0ull) break;
-    if (tid == 0) {
-      const int i = (int)((win >> 16) & 0xffff), j = (int)(win & 0xffff);
-      const int c = s_count;
-      oi[2 * c] = partA * off + i * 3 + 2;
-      oi[2 * c + 1] = partB * off + j * 3 + 2;
-      os[c] = __uint_as_float((unsigned)(win >> 32));
-      s_count = c + 1;
-      s_occA[i - 1] = 1;
-      s_occB[j - 1] = 1;
-      s_best = 0ull;
+  };
+  while (nlist > 0) {
+    for (int i = tid; i < P1; i += 256) {
+      s_bestA[i] = 0ull;
+      s_bestB[i] = 0ull;
     }
+    if (tid == 0) s_best = 0ull;  // "something was selected this round"
     __syncthreads();
+    for_each_free([&](unsigned long long key, int i, int j) {
+      atomicMax(&s_bestA[i], key);
+      atomicMax(&s_bestB[j], key);
+    });
+    __syncthreads();
+    for_each_free([&](unsigned long long key, int i, int j) {
+      if (s_bestA[i] == key && s_bestB[j] == key) {
+        s_sel[atomicAdd(&s_count, 1)] = key;
+        s_best = 1ull;
+      }
+    });
+    __syncthreads();
+    // mark after the round so that the scans above saw one consistent state
+    const int nsel = s_count;
+    for (int q = tid; q < nsel; q += 256) {
+      const unsigned long long key = s_sel[q];
+      s_occA[(int)((key >> 16) & 0xffff) - 1] = 1;
+      s_occB[(int)(key & 0xffff) - 1] = 1;
+    }
+    const bool progressed = s_best != 0ull;
+    __syncthreads();
+    if (!progressed) break;
+  }
+  const int nsel = s_count;
+  for (int q = tid; q < nsel; q += 256) {
+    const unsigned long long key = s_sel[q];
+    int rank = 0;
+    for (int r = 0; r < nsel; r++) rank += s_sel[r] > key;
+    const int i = (int)((key >> 16) & 0xffff), j = (int)(key & 0xffff);
+    oi[2 * rank] = partA * off + i * 3 + 2;
+    oi[2 * rank + 1] = partB * off + j * 3 + 2;
+    os[rank] = __uint_as_float((unsigned)(key >> 32));
   }
   if (tid == 0) *out_n = s_count;
 }
 
 // ---------------------------------------------------------------------------
 // kernel 3: person assembly + filter + pack.  grid (B), block 64 (one wave)
-// The serial part touches LDS only: peak scores, the current limb's
-// connection list and the person table are staged there.
+//
+// Upstream walks the limbs in order and, per limb, its connections in order.
+// Within ONE limb the connections have pairwise distinct A peaks and distinct B
+// peaks (greedy matching), look rows up by the A slot only and write the B slot,
+// the count and the score, so they touch disjoint rows: they are processed in
+// parallel, one lane per connection, and rows that must be appended get their
+// positions from a prefix sum in connection order.  `s_owner[part][peak]` is a
+// hint = lowest row that was ever given that peak in that slot; it is verified
+// on use and a miss falls back to the exact linear "first row" search.
+// Everything the serial dependency chain touches lives in LDS.
 // ---------------------------------------------------------------------------
 #define ASM_MAX_PARTS 32
+#define ASM_NO_ROW 0xffff
 
 __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ peaks, PhV2Dev mdl,
                                                       const int* __restrict__ conn_idx,
@@ -415,112 +450,156 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
                                                       int* __restrict__ subsets, int* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int NP = mdl.n_parts, P1 = mdl.max_peaks + 1, off = 3 * P1;
+  const int NP = mdl.n_parts, MP = mdl.max_peaks, P1 = MP + 1, off = 3 * P1;
   const int RW = NP + 1;  // uint16 words per row (last = part count)
-  float* s_score = smem;                          // row_cap
-  float* s_pk = s_score + row_cap;                // NP * P1 peak scores ([part][0] = count)
-  float* s_cs = s_pk + NP * P1;                   // max_peaks connection scores
-  int* s_ci = (int*)(s_cs + mdl.max_peaks);       // 2 * max_peaks
-  unsigned short* s_rows = (unsigned short*)(s_ci + 2 * mdl.max_peaks);  // row_cap * RW
+  float* s_score = smem;                            // row_cap
+  float* s_pk = s_score + row_cap;                  // NP * P1 peak scores ([part][0] = count)
+  float* s_cs = s_pk + NP * P1;                     // MP connection scores
+  int* s_ci = (int*)(s_cs + MP);                    // 2 * MP connection peak indices
+  int* s_owner = s_ci + 2 * MP;                     // NP * P1 row hints
+  unsigned short* s_mapA = (unsigned short*)(s_owner + NP * P1);  // P1: ear limb, peak i of A -> conn
+  unsigned short* s_mapB = s_mapA + P1 + (P1 & 1);                // P1
+  unsigned short* s_rows = s_mapB + P1 + (P1 & 1);                // row_cap * RW
   __shared__ int s_nrows;
   __shared__ int s_nc[64];
   const float* pk = peaks + (size_t)b * NP * off;
   for (int i = lane; i < NP * P1; i += 64) {
     const int part = i / P1, k = i - part * P1;
     s_pk[i] = k == 0 ? pk[part * off] : pk[part * off + k * 3 + 2];
+    s_owner[i] = 0x7fffffff;
   }
   for (int i = lane; i < mdl.n_pairs; i += 64) s_nc[i] = n_conn[(size_t)b * mdl.n_pairs + i];
   if (lane == 0) s_nrows = 0;
   __syncthreads();
-  // score of the peak with upstream index idx = part*off + i*3 + 2
-  auto pscore = [&](int idx) -> float { return s_pk[(idx / off) * P1 + (idx % off) / 3]; };
+  // upstream peak index idx = part*off + i*3 + 2  ->  slot of (part, i) in the [NP][P1] tables
+  auto slot_of = [&](int idx) -> int { return (idx / off) * P1 + (idx % off) / 3; };
 
-  auto add_row = [&](int pa, int ia, int pb, int ib, int cnt, float sc) {  // lane 0 only
-    const int r = s_nrows;
-    if (r >= row_cap) {
-      *overflow = 1;
-      return;
-    }
+  // exact "first row whose slot `part` holds idx" (verified hint, else linear search)
+  auto first_row = [&](int part, int idx, int n) -> int {
+    const int h = s_owner[slot_of(idx)];
+    if (h == 0x7fffffff) return -1;  // never assigned anywhere
+    if (h < n && s_rows[h * RW + part] == (unsigned short)idx) return h;
+    for (int r = 0; r < n; r++)
+      if (s_rows[r * RW + part] == (unsigned short)idx) return r;
+    return -1;
+  };
+  auto write_row = [&](int r, int pa, int ia, int pb, int ib, int cnt, float sc) {
     unsigned short* row = s_rows + r * RW;
     for (int k = 0; k < NP; k++) row[k] = 0;
     row[pa] = (unsigned short)ia;
-    if (pb >= 0) row[pb] = (unsigned short)ib;
+    atomicMin(&s_owner[slot_of(ia)], r);
+    if (pb >= 0) {
+      row[pb] = (unsigned short)ib;
+      atomicMin(&s_owner[slot_of(ib)], r);
+    }
     row[NP] = (unsigned short)cnt;
     s_score[r] = sc;
-    s_nrows = r + 1;
   };
-  // first row whose slot `part` holds idx, or -1 (wave-parallel search)
-  auto find_row = [&](int part, int idx) -> int {
-    const int n = s_nrows;
-    for (int r0 = 0; r0 < n; r0 += 64) {
-      const int r = r0 + lane;
-      const bool hit = r < n && s_rows[r * RW + part] == (unsigned short)idx;
-      const unsigned long long m = __ballot(hit);
-      if (m) return r0 + __ffsll((long long)m) - 1;
-    }
-    return -1;
+  // ordered append: lanes with want=true get consecutive rows after `base`, in lane order
+  auto alloc_rows = [&](bool want, int base, int* total) -> int {
+    const unsigned long long m = __ballot(want);
+    *total = __popcll(m);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
   };
 
   for (int pair = 0; pair < mdl.n_pairs; pair++) {
     const int partA = mdl.pairs[2 * pair], partB = mdl.pairs[2 * pair + 1];
     const int nA = pir(s_pk[partA * P1]), nB = pir(s_pk[partB * P1]);
     if (nA == 0 || nB == 0) {
+      // add the non-empty side's peaks nobody holds yet as single-part people (in peak order)
       const int part = nA == 0 ? partB : partA;
       const int n = nA == 0 ? nB : nA;
-      for (int i = 1; i <= n; i++) {
+      for (int i0 = 1; i0 <= n; i0 += 64) {
+        const int i = i0 + lane;
+        const int nrows = s_nrows;
         const int idx = part * off + i * 3 + 2;
-        const int f = find_row(part, idx);
-        if (f < 0 && lane == 0) add_row(part, idx, -1, 0, 1, s_pk[part * P1 + i]);
+        const bool want = i <= n && first_row(part, idx, nrows) < 0;
+        int tot;
+        const int r = alloc_rows(want, nrows, &tot);
+        if (want) {
+          if (r < row_cap) write_row(r, part, idx, -1, 0, 1, s_pk[part * P1 + i]);
+          else *overflow = 1;
+        }
+        __syncthreads();
+        if (lane == 0) s_nrows = nrows + tot < row_cap ? nrows + tot : row_cap;
         __syncthreads();
       }
       continue;
     }
     const int nc = s_nc[pair];
     if (nc == 0) continue;
-    const int* gci = conn_idx + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * 2;
-    const float* gcs = conn_score + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks;
+    const int* gci = conn_idx + ((size_t)b * mdl.n_pairs + pair) * MP * 2;
+    const float* gcs = conn_score + ((size_t)b * mdl.n_pairs + pair) * MP;
     for (int i = lane; i < 2 * nc; i += 64) s_ci[i] = gci[i];
     for (int i = lane; i < nc; i += 64) s_cs[i] = gcs[i];
-    __syncthreads();
-    if (pair == 0) {
-      if (lane == 0)
-        for (int c = 0; c < nc; c++) {
-          const int ia = s_ci[2 * c], ib = s_ci[2 * c + 1];
-          add_row(partA, ia, partB, ib, 2, (pscore(ia) + pscore(ib)) + s_cs[c]);
-        }
-      __syncthreads();
-    } else if (pair == mdl.ear_pair0 || pair == mdl.ear_pair1) {
-      for (int c = 0; c < nc; c++) {
-        const int ia = s_ci[2 * c], ib = s_ci[2 * c + 1];
-        const int n = s_nrows;
-        for (int r = lane; r < n; r += 64) {
-          unsigned short* row = s_rows + r * RW;
-          if (row[partA] == ia && row[partB] == 0)
-            row[partB] = (unsigned short)ib;
-          else if (row[partB] == ib && row[partA] == 0)
-            row[partA] = (unsigned short)ia;
-        }
-        __syncthreads();
+    const bool ear = pair == mdl.ear_pair0 || pair == mdl.ear_pair1;
+    if (ear && pair != 0)
+      for (int i = lane; i < P1; i += 64) {
+        s_mapA[i] = ASM_NO_ROW;
+        s_mapB[i] = ASM_NO_ROW;
       }
-    } else {
-      for (int c = 0; c < nc; c++) {
-        const int ia = s_ci[2 * c], ib = s_ci[2 * c + 1];
-        const float s = s_cs[c];
-        const int f = find_row(partA, ia);
-        if (lane == 0) {
-          if (f >= 0) {
-            unsigned short* row = s_rows + f * RW;
-            row[partB] = (unsigned short)ib;
-            row[NP] = row[NP] + 1;
-            s_score[f] = s_score[f] + (pscore(ib) + s);
-          } else {
-            add_row(partA, ia, partB, ib, 2, (pscore(ia) + pscore(ib)) + s);
+    __syncthreads();
+    if (ear && pair != 0) {
+      // rows holding A (resp. B) of a connection and nothing in the other slot get the partner;
+      // connections have distinct A's and B's, so each row matches at most one of them
+      for (int c = lane; c < nc; c += 64) {
+        s_mapA[(s_ci[2 * c] % off) / 3] = (unsigned short)c;
+        s_mapB[(s_ci[2 * c + 1] % off) / 3] = (unsigned short)c;
+      }
+      __syncthreads();
+      const int n = s_nrows;
+      for (int r = lane; r < n; r += 64) {
+        unsigned short* row = s_rows + r * RW;
+        const int a = row[partA], bb = row[partB];
+        if (a != 0 && bb == 0) {
+          const int c = s_mapA[(a % off) / 3];
+          if (c != ASM_NO_ROW) {
+            row[partB] = (unsigned short)s_ci[2 * c + 1];
+            atomicMin(&s_owner[slot_of(s_ci[2 * c + 1])], r);
+          }
+        } else if (bb != 0 && a == 0) {
+          const int c = s_mapB[(bb % off) / 3];
+          if (c != ASM_NO_ROW) {
+            row[partA] = (unsigned short)s_ci[2 * c];
+            atomicMin(&s_owner[slot_of(s_ci[2 * c])], r);
           }
         }
-        __syncthreads();
       }
+      __syncthreads();
+      continue;
     }
-    __syncthreads();  // s_ci / s_cs are reloaded by the next limb
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+      const int c = c0 + lane;
+      const int nrows = s_nrows;
+      int ia = 0, ib = 0, f = -1;
+      float s = 0.f;
+      if (c < nc) {
+        ia = s_ci[2 * c];
+        ib = s_ci[2 * c + 1];
+        s = s_cs[c];
+        if (pair != 0) f = first_row(partA, ia, nrows);
+      }
+      const bool want = c < nc && f < 0;
+      int tot;
+      const int r = alloc_rows(want, nrows, &tot);
+      __syncthreads();  // all lookups done before any row changes
+      if (c < nc) {
+        if (f >= 0) {
+          unsigned short* row = s_rows + f * RW;
+          row[partB] = (unsigned short)ib;
+          atomicMin(&s_owner[slot_of(ib)], f);
+          row[NP] = row[NP] + 1;
+          s_score[f] = s_score[f] + (s_pk[slot_of(ib)] + s);
+        } else if (r < row_cap) {
+          write_row(r, partA, ia, partB, ib, 2, (s_pk[slot_of(ia)] + s_pk[slot_of(ib)]) + s);
+        } else {
+          *overflow = 1;
+        }
+      }
+      __syncthreads();
+      if (lane == 0) s_nrows = nrows + tot < row_cap ? nrows + tot : row_cap;
+      __syncthreads();
+    }
   }
   __syncthreads();
 
@@ -685,10 +764,11 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
                       (size_t)Wt * sizeof(TapsP) + ((size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4;
   const size_t lds1b = (size_t)hs * ws * 4;
   const size_t lds2 = (size_t)PAF_LIST_CAP * 8 + ((size_t)2 * hs * ws + (size_t)2 * (m.max_peaks + 1) * 3) * 4 +
-                      (size_t)(Wt + Ht) * sizeof(TapsP) + 2 * (m.max_peaks + 1) + 16;
+                      (size_t)(Wt + Ht + 1) * sizeof(TapsP) + (size_t)3 * (m.max_peaks + 1) * 8 +
+                      2 * (m.max_peaks + 1) + 32;
   const int row_cap = 2048;
-  const size_t lds3 = ((size_t)row_cap + (size_t)m.n_parts * (m.max_peaks + 1) + 3 * (size_t)m.max_peaks) * 4 +
-                      (size_t)row_cap * (m.n_parts + 1) * 2;
+  const size_t lds3 = ((size_t)row_cap + 2 * (size_t)m.n_parts * (m.max_peaks + 1) + 3 * (size_t)m.max_peaks) * 4 +
+                      (size_t)2 * (m.max_peaks + 2) * 2 + (size_t)row_cap * (m.n_parts + 1) * 2;
   const size_t lim = 160 * 1024 - 1024;
   if (lds1 > lim || lds1b > lim || lds2 > lim || lds3 > lim || hs > 65535 || ws > 65535) {
     ph_set_error("decode_v2: LDS budget exceeded (%zu/%zu/%zu B) for net output %dx%d target %dx%d", lds1, lds2,
