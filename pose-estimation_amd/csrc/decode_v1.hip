@@ -22,6 +22,7 @@
 
 #define V1_TILE_H 16
 #define V1_TILE_W 256
+#define V1_RUN_THREADS 1024
 
 __device__ __forceinline__ int reflect101(int p, int n) {
   if (n == 1) return 0;
@@ -82,7 +83,7 @@ __device__ __forceinline__ float resize_tab(const float* src, int ws, const LinX
 // ---------------------------------------------------------------------------
 // K-A: mask runs.  grid (tiles_x * tiles_y, n_parts, B), block 256
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void v1_runs_kernel(const float* __restrict__ net_out, int C, int hs, int ws, int W,
+__global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __restrict__ net_out, int C, int hs, int ws, int W,
                                                       int H, float thr, int n_parts, int run_cap,
                                                       int* __restrict__ n_runs, V1Run* __restrict__ runs,
                                                       int* __restrict__ overflow) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void v1_runs_kernel(const float* __restrict__ 
   float* s_heat = s_src + hs * ws;             // (TILE_H+2) * (TILE_W+2)
   float* s_t = s_heat + (V1_TILE_H + 2) * (V1_TILE_W + 2);  // (TILE_H+2) * TILE_W
   float* s_sm = s_t + (V1_TILE_H + 2) * V1_TILE_W;          // TILE_H * TILE_W
-  __shared__ float s_max[4];
+  __shared__ float s_max[V1_RUN_THREADS / 64];
   __shared__ LinX s_lx[V1_TILE_W + 2];   // per-tile coordinate tables: the fp64 coordinate
   __shared__ LinX s_ly[V1_TILE_H + 2];   // arithmetic runs once per column/row, not per pixel
 
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void v1_runs_kernel(const float* __restrict__ 
   const int sxa = lin_x(xa, W, ws).s0, sxb = lin_x(xb, W, ws).s1;
   const int sya = lin_y(ya, H, hs).s0, syb = lin_y(yb, H, hs).s1;
   float lm = -INFINITY;
-  for (int i = tid; i < hs * ws; i += 256) {
+  for (int i = tid; i < hs * ws; i += V1_RUN_THREADS) {
     const float v = plane[i];
     s_src[i] = v;
     const int yy = i / ws, xx = i - yy * ws;
@@ -115,30 +116,31 @@ __global__ __launch_bounds__(256) void v1_runs_kernel(const float* __restrict__ 
   for (int o = 32; o > 0; o >>= 1) lm = fmaxf(lm, __shfl_xor(lm, o));
   if ((tid & 63) == 0) s_max[tid >> 6] = lm;
   __syncthreads();
-  const float tile_max = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  float tile_max = s_max[0];
+  for (int i = 1; i < V1_RUN_THREADS / 64; i++) tile_max = fmaxf(tile_max, s_max[i]);
   // resize + blur are convex combinations up to a few ulps: nothing here can exceed thr
   if (thr > 0.f && tile_max < thr * 0.999f) return;
 
   // 1. bilinear-resized heat map, tile + 1-px halo, reflect-101 at the image border
   constexpr int HW_ = V1_TILE_W + 2;
-  for (int c = tid; c < HW_; c += 256)
+  for (int c = tid; c < HW_; c += V1_RUN_THREADS)
     if (x0 - 1 + c <= W) s_lx[c] = lin_x(reflect101(x0 - 1 + c, W), W, ws);
   if (tid < V1_TILE_H + 2 && y0 - 1 + tid <= H) s_ly[tid] = lin_y(reflect101(y0 - 1 + tid, H), H, hs);
   __syncthreads();
-  for (int i = tid; i < (V1_TILE_H + 2) * HW_; i += 256) {
+  for (int i = tid; i < (V1_TILE_H + 2) * HW_; i += V1_RUN_THREADS) {
     const int r = i / HW_, c = i - r * HW_;
     s_heat[i] = (y0 - 1 + r <= H && x0 - 1 + c <= W) ? resize_tab(s_src, ws, s_lx[c], s_ly[r]) : 0.f;
   }
   __syncthreads();
   // 2. row pass  c*1/2 + (l + r)*1/4
-  for (int i = tid; i < (V1_TILE_H + 2) * V1_TILE_W; i += 256) {
+  for (int i = tid; i < (V1_TILE_H + 2) * V1_TILE_W; i += V1_RUN_THREADS) {
     const int r = i / V1_TILE_W, c = i - r * V1_TILE_W;
     const float* h = s_heat + r * HW_ + c + 1;
     s_t[i] = h[0] * 0.5f + (h[-1] + h[1]) * 0.25f;
   }
   __syncthreads();
   // 3. column pass
-  for (int i = tid; i < V1_TILE_H * V1_TILE_W; i += 256) {
+  for (int i = tid; i < V1_TILE_H * V1_TILE_W; i += V1_RUN_THREADS) {
     const int r = i / V1_TILE_W, c = i - r * V1_TILE_W;
     const float* t = s_t + (r + 1) * V1_TILE_W + c;
     const bool inside = y0 + r < H && x0 + c < W;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void v1_runs_kernel(const float* __restrict__ 
   // 4. runs: the thread on a run's first pixel walks it
   int* cnt = n_runs + (size_t)b * n_parts + part;
   V1Run* out = runs + ((size_t)b * n_parts + part) * run_cap;
-  for (int i = tid; i < V1_TILE_H * V1_TILE_W; i += 256) {
+  for (int i = tid; i < V1_TILE_H * V1_TILE_W; i += V1_RUN_THREADS) {
     const int r = i / V1_TILE_W, c = i - r * V1_TILE_W;
     const float* row = s_sm + r * V1_TILE_W;
     if (row[c] > thr && (c == 0 || !(row[c - 1] > thr))) {
@@ -535,7 +537,7 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   PH_CHECK(hipMemsetAsync(w.kps, 0, sz.kps, stream));
   const int tiles = ((W + V1_TILE_W - 1) / V1_TILE_W) * ((H + V1_TILE_H - 1) / V1_TILE_H);
   if (ev) PH_CHECK(hipEventRecord(ev[0], stream));
-  hipLaunchKernelGGL(v1_runs_kernel, dim3(tiles, m.n_parts, B), dim3(256), ldsA, stream, net_out, C, hs, ws, W, H, thr,
+  hipLaunchKernelGGL(v1_runs_kernel, dim3(tiles, m.n_parts, B), dim3(V1_RUN_THREADS), ldsA, stream, net_out, C, hs, ws, W, H, thr,
                      m.n_parts, c.run_cap, w.n_runs, w.runs, w.overflow);
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(v1_blobs_kernel, dim3(m.n_parts, B), dim3(256), ldsB, stream, net_out, C, hs, ws, W, H, m.n_parts,

@@ -82,14 +82,18 @@ __device__ __forceinline__ float bicubic_at(const float* src, int hs, int ws, in
 // upsampled map and emits that stripe's peak pixels in raster order.
 // ---------------------------------------------------------------------------
 #define NMS_BAND 8
+#define NMS_TX 256  // block = NMS_TX columns x NMS_TY rows: 16 waves keep the LDS pipeline busy
+#define NMS_TY 4
 #define NMS_TRING 8  // source rows live at once: (NMS_BAND + 2) / scale + 4 taps <= 7 for scale >= 4
 
-__global__ __launch_bounds__(256) void nms_detect_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
+__global__ __launch_bounds__(NMS_TX * NMS_TY) void nms_detect_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
                                                          int Ht, int Wt, float threshold, int max_peaks, int n_parts,
                                                          int n_split, int rows_per_split, int* __restrict__ keys,
                                                          int* __restrict__ key_cnt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int part = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
+  const int part = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+  const int tx_ = threadIdx.x, ty_ = threadIdx.y, tid = ty_ * NMS_TX + tx_;
+  constexpr int NT = NMS_TX * NMS_TY;
   float* s_src = smem;                                   // hs*ws
   float* s_T = s_src + hs * ws;                          // NMS_TRING * Wt : source row r at slot r & 7
   float* s_U = s_T + NMS_TRING * Wt;                     // (NMS_BAND+2) * Wt
@@ -100,8 +104,8 @@ __global__ __launch_bounds__(256) void nms_detect_kernel(const float* __restrict
   __shared__ int s_ncand;
 
   const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
-  for (int i = tid; i < hs * ws; i += 256) s_src[i] = plane[i];
-  for (int x = tid; x < Wt; x += 256) s_xt[x] = pack_taps(src_taps(x, Wt, ws));
+  for (int i = tid; i < hs * ws; i += NT) s_src[i] = plane[i];
+  for (int x = tid; x < Wt; x += NT) s_xt[x] = pack_taps(src_taps(x, Wt, ws));
   if (tid == 0) s_ncand = 0;
   __syncthreads();
 
@@ -119,16 +123,16 @@ __global__ __launch_bounds__(256) void nms_detect_kernel(const float* __restrict
     const int shi = src_taps(yhi, Ht, hs).i3;
     // 1. horizontal cubic of the source rows not yet in the ring
     const int t_first = t_done + 1 > slo ? t_done + 1 : slo;
-    for (int x = tid; x < Wt; x += 256) {
+    for (int x = tx_; x < Wt; x += NMS_TX) {
       const TapsP tx = s_xt[x];
-      for (int sr = t_first; sr <= shi; sr++)
+      for (int sr = t_first + ty_; sr <= shi; sr += NMS_TY)
         s_T[(sr & (NMS_TRING - 1)) * Wt + x] = cubic_row(s_src + sr * ws, tx);
     }
     t_done = shi;
     __syncthreads();
     // 2. vertical cubic -> upsampled band with a 1-row halo
-    for (int x = tid; x < Wt; x += 256)
-      for (int rr = 0; rr < nrows_u; rr++) {
+    for (int x = tx_; x < Wt; x += NMS_TX)
+      for (int rr = ty_; rr < nrows_u; rr += NMS_TY) {
         const TapsP ty = s_yt[rr];
         s_U[rr * Wt + x] =
             cubic(s_T[(ty.i0 & (NMS_TRING - 1)) * Wt + x], s_T[(ty.i1 & (NMS_TRING - 1)) * Wt + x],
@@ -139,8 +143,8 @@ __global__ __launch_bounds__(256) void nms_detect_kernel(const float* __restrict
     const int y_first = r0 < 1 ? 1 : r0;
     int y_last = r0 + NMS_BAND - 1 > Ht - 2 ? Ht - 2 : r0 + NMS_BAND - 1;
     y_last = y_last > y_end - 1 ? y_end - 1 : y_last;
-    for (int x = tid + 1; x < Wt - 1; x += 256)
-      for (int y = y_first; y <= y_last; y++) {
+    for (int x = tx_ + 1; x < Wt - 1; x += NMS_TX)
+      for (int y = y_first + ty_; y <= y_last; y += NMS_TY) {
         const float* u = s_U + (y - ylo) * Wt + x;
         const float v = u[0];
         if (v > threshold) {
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void nms_detect_kernel(const float* __restrict
     __syncthreads();
     // 4. raster order inside the band by rank; keep the first max_peaks of the stripe
     const int n = s_ncand;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
       const int key = s_cand[i];
       int rank = 0;
       for (int j = 0; j < n; j++) rank += s_cand[j] < key;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void nms_detect_kernel(const float* __restrict
   }
   const int count = base < max_peaks ? base : max_peaks;
   int* out = keys + (((size_t)b * n_parts + part) * n_split + sp) * max_peaks;
-  for (int k = tid; k < count; k += 256) out[k] = s_keys[k];
+  for (int k = tid; k < count; k += NT) out[k] = s_keys[k];
   if (tid == 0) key_cnt[((size_t)b * n_parts + part) * n_split + sp] = count;
 }
 
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(128) void nms_refine_kernel(const float* __restrict
 __device__ __forceinline__ int pir(float x) { return (int)(x + 0.5f); }
 
 #define PAF_LIST_CAP 2048
+#define PAF_THREADS 1024
 
 __device__ float score_ab(const float* A, const float* Bp, const float* mapx, const float* mapy, int ws, int Ht,
                           int Wt, const TapsP* xt, const TapsP* yt, float inter_thr, float inter_min_above,
@@ -283,7 +288,7 @@ __device__ float score_ab(const float* A, const float* Bp, const float* mapx, co
   return 0.f;
 }
 
-__global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
+__global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
                                                         int Ht, int Wt, const float* __restrict__ peaks,
                                                         PhV2Dev mdl, float* __restrict__ pair_scores,
                                                         int* __restrict__ conn_idx, float* __restrict__ conn_score,
@@ -317,20 +322,20 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
 
   const float* px = net_out + ((size_t)b * C + mdl.n_heat + mdl.mapidx[2 * pair]) * hs * ws;
   const float* py = net_out + ((size_t)b * C + mdl.n_heat + mdl.mapidx[2 * pair + 1]) * hs * ws;
-  for (int i = tid; i < hs * ws; i += 256) {
+  for (int i = tid; i < hs * ws; i += PAF_THREADS) {
     s_mx[i] = px[i];
     s_my[i] = py[i];
   }
-  for (int i = tid; i < P1 * 3; i += 256) {
+  for (int i = tid; i < P1 * 3; i += PAF_THREADS) {
     s_A[i] = candA[i];
     s_B[i] = candB[i];
   }
-  for (int i = tid; i < P1; i += 256) {
+  for (int i = tid; i < P1; i += PAF_THREADS) {
     s_occA[i] = 0;
     s_occB[i] = 0;
   }
-  for (int x = tid; x < Wt; x += 256) s_xt[x] = pack_taps(src_taps(x, Wt, ws));
-  for (int y = tid; y < Ht; y += 256) s_yt[y] = pack_taps(src_taps(y, Ht, hs));
+  for (int x = tid; x < Wt; x += PAF_THREADS) s_xt[x] = pack_taps(src_taps(x, Wt, ws));
+  for (int y = tid; y < Ht; y += PAF_THREADS) s_yt[y] = pack_taps(src_taps(y, Ht, hs));
   if (tid == 0) {
     s_best = 0ull;
     s_count = 0;
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
 
   float* sc = pair_scores + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * mdl.max_peaks;
   const int npairs = nA * nB;
-  for (int p = tid; p < npairs; p += 256) {
+  for (int p = tid; p < npairs; p += PAF_THREADS) {
     const int i = p / nB, j = p - i * nB;  // 0-based
     const float s = score_ab(s_A + (i + 1) * 3, s_B + (j + 1) * 3, s_mx, s_my, ws, Ht, Wt, s_xt, s_yt,
                              mdl.inter_threshold, mdl.inter_min_above, mdl.close_thr, mdl.close_score);
@@ -366,13 +371,13 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
   const int off = 3 * P1;
   auto for_each_free = [&](auto&& fn) {
     if (use_list) {
-      for (int q = tid; q < nlist; q += 256) {
+      for (int q = tid; q < nlist; q += PAF_THREADS) {
         const unsigned long long key = s_list[q];
         const int i = (int)((key >> 16) & 0xffff) - 1, j = (int)(key & 0xffff) - 1;
         if (!s_occA[i] && !s_occB[j]) fn(key, i, j);
       }
     } else {
-      for (int p = tid; p < npairs; p += 256) {
+      for (int p = tid; p < npairs; p += PAF_THREADS) {
         const float s = sc[p];
         if ((double)s > 1e-6) {
           const int i = p / nB, j = p - i * nB;
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
     }
   };
   while (nlist > 0) {
-    for (int i = tid; i < P1; i += 256) {
+    for (int i = tid; i < P1; i += PAF_THREADS) {
       s_bestA[i] = 0ull;
       s_bestB[i] = 0ull;
     }
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
     __syncthreads();
     // mark after the round so that the scans above saw one consistent state
     const int nsel = s_count;
-    for (int q = tid; q < nsel; q += 256) {
+    for (int q = tid; q < nsel; q += PAF_THREADS) {
       const unsigned long long key = s_sel[q];
       s_occA[(int)((key >> 16) & 0xffff) - 1] = 1;
       s_occB[(int)(key & 0xffff) - 1] = 1;
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(256) void paf_match_kernel(const float* __restrict_
     if (!progressed) break;
   }
   const int nsel = s_count;
-  for (int q = tid; q < nsel; q += 256) {
+  for (int q = tid; q < nsel; q += PAF_THREADS) {
     const unsigned long long key = s_sel[q];
     int rank = 0;
     for (int r = 0; r < nsel; r++) rank += s_sel[r] > key;
@@ -788,12 +793,12 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   PH_CHECK(hipMemsetAsync(w.peaks, 0, sz.peaks, stream));
   PH_CHECK(hipMemsetAsync(w.overflow, 0, sizeof(int), stream));
   if (ev) PH_CHECK(hipEventRecord(ev[0], stream));
-  hipLaunchKernelGGL(nms_detect_kernel, dim3(m.n_parts, B, n_split), dim3(256), lds1, stream, net_out, C, hs, ws, Ht,
+  hipLaunchKernelGGL(nms_detect_kernel, dim3(m.n_parts, B, n_split), dim3(NMS_TX, NMS_TY), lds1, stream, net_out, C, hs, ws, Ht,
                      Wt, m.nms_threshold, m.max_peaks, m.n_parts, n_split, rows_per_split, w.nms_keys, w.nms_cnt);
   hipLaunchKernelGGL(nms_refine_kernel, dim3(m.n_parts, B), dim3(128), lds1b, stream, net_out, C, hs, ws, Ht, Wt,
                      m.max_peaks, m.n_parts, n_split, (const int*)w.nms_keys, (const int*)w.nms_cnt, w.peaks);
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
-  hipLaunchKernelGGL(paf_match_kernel, dim3(m.n_pairs, B), dim3(256), lds2, stream, net_out, C, hs, ws, Ht, Wt,
+  hipLaunchKernelGGL(paf_match_kernel, dim3(m.n_pairs, B), dim3(PAF_THREADS), lds2, stream, net_out, C, hs, ws, Ht, Wt,
                      (const float*)w.peaks, m, w.pair_scores, w.conn_idx, w.conn_score, w.n_conn);
   if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
   hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(64), lds3, stream, (const float*)w.peaks, m,
