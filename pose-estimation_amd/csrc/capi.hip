@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -13,7 +14,7 @@
 #include "decode_v1.h"
 #include "decode_v2.h"
 
-int ph_launch_conv(const PhConvParams& p, int nrep, hipStream_t stream);
+int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t stream);
 int ph_launch_maxpool(const bf16* in, bf16* out, int B, int H, int W, int C, int in_Hp, int in_Wp, int in_Cs,
                       int in_org, int oH, int oW, int out_Hp, int out_Wp, int out_Cs, int out_org,
                       hipStream_t stream);
@@ -43,6 +44,7 @@ struct Op {
   ph_op_desc d;
   PhConvParams cp;   // conv: device-ready parameters (B-dependent fields patched per call)
   int nrep = 0;
+  int variant = 0;
   bf16* wt = nullptr;
   float* bias = nullptr;
   float* slope = nullptr;
@@ -307,7 +309,11 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       return -1;
     }
     o.nrep = tn / 32;
-    const int cout_pad = (d.cout + tn - 1) / tn * tn;
+    const int cout_pad = (d.cout + 127) / 128 * 128;
+    {
+      const char* ev = getenv("POSEHIP_CONV_KERNEL");
+      o.variant = ev ? atoi(ev) : 0;
+    }
     const int K = d.kh * d.kw * d.cin_read;
     const int Kpad = (K + 63) / 64 * 64;
     if ((unsigned long long)Kpad * d.cin_read >= 0xffffffffull) {
@@ -328,7 +334,7 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
           w[(size_t)n * Kpad + t * d.cin_read + cc] =
               f32_to_bf16(d.weight[((size_t)n * d.cin_caffe + src) * d.kh * d.kw + t]);
         }
-    std::vector<float> bias(cout_pad, 0.f), slope(cout_pad, 0.f);
+    std::vector<float> bias(cout_pad + 128, 0.f), slope(cout_pad + 128, 0.f);  // tiles stage 128 entries from n0
     if (d.bias) memcpy(bias.data(), d.bias, d.cout * sizeof(float));
     if (d.act == PH_ACT_PRELU) {
       if (!d.slope || (d.slope_count != 1 && d.slope_count != d.cout)) {
@@ -338,11 +344,11 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       for (int n = 0; n < d.cout; n++) slope[n] = d.slope[d.slope_count == 1 ? 0 : n];
     }
     PH_CHECK(hipMalloc(&o.wt, w.size() * 2));
-    PH_CHECK(hipMalloc(&o.bias, cout_pad * sizeof(float)));
-    PH_CHECK(hipMalloc(&o.slope, cout_pad * sizeof(float)));
+    PH_CHECK(hipMalloc(&o.bias, bias.size() * sizeof(float)));
+    PH_CHECK(hipMalloc(&o.slope, slope.size() * sizeof(float)));
     PH_CHECK(hipMemcpy(o.wt, w.data(), w.size() * 2, hipMemcpyHostToDevice));
-    PH_CHECK(hipMemcpy(o.bias, bias.data(), cout_pad * sizeof(float), hipMemcpyHostToDevice));
-    PH_CHECK(hipMemcpy(o.slope, slope.data(), cout_pad * sizeof(float), hipMemcpyHostToDevice));
+    PH_CHECK(hipMemcpy(o.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    PH_CHECK(hipMemcpy(o.slope, slope.data(), slope.size() * sizeof(float), hipMemcpyHostToDevice));
     PhConvParams& p = o.cp;
     memset(&p, 0, sizeof(p));
     p.in = in.ptr;
@@ -363,6 +369,13 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
     p.magic_cin = ph_magic(d.cin_read);
     p.magic_kw = ph_magic(d.kw);
     p.cout = d.cout;
+    p.cout_pad = cout_pad;
+    {
+      const char* ev = getenv("POSEHIP_CONV_DEBUG");
+      const char* eo = getenv("POSEHIP_CONV_DEBUG_OP");
+      p.debug = ev ? atoi(ev) : 0;
+      if (eo && atoi(eo) != i) p.debug = 0;
+    }
     p.act = d.act;
     p.n_dst = d.n_dst;
     for (int k = 0; k < d.n_dst; k++) {
@@ -439,7 +452,7 @@ static int run_ops(ph_ctx* c, int B, bool timed) {
     } else {
       o.cp.B = B;
       o.cp.M = B * o.cp.H * o.cp.W;
-      if (ph_launch_conv(o.cp, o.nrep, c->stream)) return -1;
+      if (ph_launch_conv(o.cp, o.nrep, o.variant, c->stream)) return -1;
     }
   }
   if (timed) PH_CHECK(hipEventRecord(c->op_ev[c->ops.size()], c->stream));

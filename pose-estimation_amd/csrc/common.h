@@ -28,12 +28,13 @@ struct PhConvParams {
   int in_org;        // element offset of tap (0,0) of output pixel (0,0,0)
   int cin_read, KW, K, Kpad, nk;
   unsigned magic_cin, magic_kw;
-  int cout, act;     // act: 0 none, 1 ReLU, 2 PReLU
+  int cout, cout_pad, act;  // act: 0 none, 1 ReLU, 2 PReLU; cout_pad = rows of wt / bias / slope
   int n_dst;
   PhDst dst[PH_MAX_DST];
   float* f32_out;    // optional NCHW fp32 [B][f32_C][H][W] written at f32_coff
   int f32_C, f32_coff;
   int n_mtiles, n_ntiles;
+  int debug;  // timing experiments only (POSEHIP_CONV_DEBUG): 1 skip A loads, 2 skip B loads, 4 skip MFMA
 };
 
 __host__ __device__ static inline unsigned ph_magic(unsigned d) {

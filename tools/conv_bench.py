@@ -52,10 +52,22 @@ def main():
         eng.build(plan, B)
         eng.preprocess(synth.synth_frames(0, B, H, W), _ffi.PH_PRE_CV2)
         ts = []
+        dbg = int(os.environ.get("POSEHIP_CONV_DEBUG", "0")) & 8
+        import ctypes
+        L = _ffi.lib()
+        cyc = (ctypes.c_ulonglong * 8)()
         for r in range(args.reps + 3):
+            if r == 3 and dbg:
+                eng.sync()
+                L.ph_debug_conv_cycles(cyc, 1)
             ms = eng.forward_timed(B)
             if r >= 3:
                 ts.append(ms[1])
+        if dbg:
+            eng.sync()
+            L.ph_debug_conv_cycles(cyc, 0)
+            nb = max(1, cyc[4])
+            print(f"  blocks {nb // args.reps}: prologue {cyc[0] / nb:.0f}  kloop {cyc[1] / nb:.0f} (wait {cyc[3] / nb:.0f})  epilogue {cyc[2] / nb:.0f} cycles/block")
         t = float(np.median(ts))
         fl = 2.0 * k * k * cin * cout * H * W * B
         print(f"{name:10s} {H}x{W} {cin:4d}->{cout:4d} k{k}: {t:8.4f} ms  {fl / t / 1e9:8.1f} TFLOP/s", flush=True)
