@@ -15,6 +15,7 @@
 #include "decode_v2.h"
 
 int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t stream);
+bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32);
 int ph_launch_maxpool(const bf16* in, bf16* out, int B, int H, int W, int C, int in_Hp, int in_Wp, int in_Cs,
                       int in_org, int oH, int oW, int out_Hp, int out_Wp, int out_Cs, int out_org,
                       hipStream_t stream);
@@ -310,10 +311,6 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
     }
     o.nrep = tn / 32;
     const int cout_pad = (d.cout + 127) / 128 * 128;
-    {
-      const char* ev = getenv("POSEHIP_CONV_KERNEL");
-      o.variant = ev ? atoi(ev) : 0;
-    }
     const int K = d.kh * d.kw * d.cin_read;
     const int Kpad = (K + 63) / 64 * 64;
     if ((unsigned long long)Kpad * d.cin_read >= 0xffffffffull) {
@@ -389,6 +386,19 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
     p.f32_out = d.f32_coff >= 0 ? c->net_out : nullptr;
     p.f32_C = out_channels;
     p.f32_coff = d.f32_coff >= 0 ? d.f32_coff : 0;
+    p.B = batch;
+    p.M = batch * in.d.height * in.d.width;
+    p.in_pad = in.d.pad;
+    p.in_coff = d.in_coff;
+    p.NQ = batch * in.Hp() * in.Wp();
+    {
+      // kernel choice: POSEHIP_CONV_KERNEL=0/2/3 forces the im2col-gather kernels, default picks the
+      // 3x3 halo-patch kernel wherever it applies
+      const char* ev = getenv("POSEHIP_CONV_KERNEL");
+      const int want = ev ? atoi(ev) : 4;
+      o.variant = want;
+      if (want == 4 && !ph_conv_halo_plan(p, d.kh, d.f32_coff >= 0)) o.variant = 0;
+    }
     int real_cin = 0;
     for (int cc = 0; cc < d.cin_read; cc++) real_cin += d.cin_map[cc] >= 0;
     o.flops = 2.0 * d.kh * d.kw * real_cin * d.cout * in.d.height * in.d.width;
@@ -452,6 +462,7 @@ static int run_ops(ph_ctx* c, int B, bool timed) {
     } else {
       o.cp.B = B;
       o.cp.M = B * o.cp.H * o.cp.W;
+      if (o.variant == 4) ph_conv_halo_plan(o.cp, 3, false);  // tile count follows B
       if (ph_launch_conv(o.cp, o.nrep, o.variant, c->stream)) return -1;
     }
   }

@@ -34,6 +34,15 @@ struct PhConvParams {
   float* f32_out;    // optional NCHW fp32 [B][f32_C][H][W] written at f32_coff
   int f32_C, f32_coff;
   int n_mtiles, n_ntiles;
+  // 3x3 halo-patch kernel (conv3x3_halo_kernel) geometry, filled by ph_net_build
+  int in_pad, in_coff;   // border width of the input buffer, first channel of the read window
+  int NQ;                // pixels of the padded input buffer (B * Hp * Wp)
+  int halo_mode;         // 0: tiles are 256-pixel runs of the padded linear domain, 1: 16x16 pixel tiles
+  int q_first;           // mode 0: padded linear index of output pixel (0,0,0)
+  int tiles_x, tiles_y;  // mode 1
+  int SKH, SI;           // patch pixel of (row block i, px, kh, kw) = kh*SKH + i*SI + kw + px
+  int PR, PCLIP, NI;     // patch pixel j <-> input pixel Qbase + j + min(j/PR, PCLIP)*(Wp-PR); NI 16-pixel pieces
+  unsigned magic_pr;
   int debug;  // timing experiments only (POSEHIP_CONV_DEBUG): 1 skip A loads, 2 skip B loads, 4 skip MFMA
 };
 

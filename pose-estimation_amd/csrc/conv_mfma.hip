@@ -516,8 +516,391 @@ static int launch_s(const PhConvParams& p, hipStream_t stream) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 halo-patch kernel.  The im2col gather above re-reads every input pixel 9x
+// through the L2 -> LDS path, and that path (~35-40 B/clk/CU measured), not the
+// MFMA, bounds it.  Here a block owns 256 output pixels x BN channels and, per
+// 32-channel chunk of Cin, brings the input PATCH (the pixels any of the 9 taps
+// touch) into LDS once; the 9 taps then read shifted windows of the patch, and
+// only the 128 x 32 weight slice of each (tap, chunk) is streamed per K step.
+//
+// Output pixels are enumerated either as a 256-long run of the PADDED linear
+// pixel index (mode 0: the patch is the run widened by Wp+1 on both sides; the
+// outputs that fall on border pixels are computed and dropped -- 46x82 maps: 7 %),
+// or as 16x16 tiles (mode 1: 18x18 patch).  4 waves as 2 (M) x 2 (N), wave tile
+// 128 x BN/2 (acc 8 x NREP MFMA tiles), two patch buffers (chunk c+1 arrives in 8
+// pieces during the 9 steps of chunk c), three weight-slice slots, counted vmcnt,
+// one barrier per K step, 2 blocks per CU.
+// LDS rows are 64 B; k-chunk c of patch pixel / weight row r sits in slot
+// c ^ ((r >> 1) & 2): conflict-free ds_read_b128 for ANY 16 consecutive rows.
+// ---------------------------------------------------------------------------
+#define HALO_BM 256
+
+template <int NREP, bool DBG>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams p) {
+  constexpr int BN = 32 * NREP;
+  constexpr bool PIPE = NREP < 4;              // cross-step fragment prefetch (registers allow it below NREP 4)
+  constexpr int NBI = BN / 16;                 // 16-row weight staging instructions per K step
+  constexpr int B_STAGE = NBI * 1024;
+  constexpr int NBS = 3;
+  constexpr int CROWB = BN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int patch_bytes = p.NI * 1024;
+  char* const bring = lds + 2 * patch_bytes;
+  float* const s_bias = (float*)(bring + NBS * B_STAGE);
+  float* const s_slope = s_bias + 128;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const bool dbg_t = DBG && (p.debug & 8) != 0;
+  long long t0 = 0, t1 = 0, t2 = 0, tw = 0;
+  if (dbg_t) t0 = clock64();
+
+  const unsigned nblk = gridDim.x;
+  const unsigned bid = blockIdx.x;
+  const unsigned xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int mt = logical / p.n_ntiles;
+  const int nt = logical - mt * p.n_ntiles;
+  const int n0 = nt * BN;
+  const int Wp = p.in_Wp, Hp = p.in_Hp, pi = p.in_pad;
+
+  // tile geometry: centre index of output row 0 / of the patch origin
+  int Qc0, rowstep;  // output row r = 16*i + px has centre Qc0 + i*rowstep + px
+  if (p.halo_mode == 0) {
+    Qc0 = p.q_first + mt * HALO_BM;
+    rowstep = 16;
+  } else {
+    const int tx = mt % p.tiles_x;
+    const int t2 = mt / p.tiles_x;
+    const int ty = t2 % p.tiles_y;
+    const int b = t2 / p.tiles_y;
+    Qc0 = (b * Hp + ty * 16 + pi) * Wp + tx * 16 + pi;
+    rowstep = Wp;
+  }
+  const int Qbase = Qc0 - Wp - 1;
+
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  {  // bias / slope -> LDS
+    const float* src = (wave < 2 ? p.bias : p.slope) + n0 + (wave & 1) * 64 + lane;
+    float* dst = (wave < 2 ? s_bias : s_slope) + (wave & 1) * 64;
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 4, 0, 0);
+  }
+
+  // ---- staging addresses -----------------------------------------------------
+  const int lchunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);   // source k-chunk of this lane's slot
+  unsigned a_src[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    int idx = u * 4 + wave;
+    idx = idx < p.NI ? idx : p.NI - 1;
+    const int j = idx * 16 + (lane >> 2);
+    int jr = (int)ph_div((unsigned)j, p.magic_pr, (unsigned)p.PR);
+    jr = jr < p.PCLIP ? jr : p.PCLIP;
+    int Q = Qbase + j + jr * (Wp - p.PR);
+    Q = Q < 0 ? 0 : (Q < p.NQ ? Q : p.NQ - 1);
+    a_src[u] = (unsigned)Q * (unsigned)p.in_Cs + (unsigned)(p.in_coff + lchunk * 8);
+  }
+  unsigned w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    int n = n0 + (wave + i * 4) * 16 + (lane >> 2);
+    n = n < p.cout_pad ? n : p.cout_pad - 1;
+    w_src[i] = (unsigned)n * (unsigned)p.Kpad + (unsigned)(lchunk * 8);
+  }
+  const int nb_w = (wave < NBI ? 1 : 0) + (wave + 4 < NBI ? 1 : 0);  // weight instructions of this wave per step
+
+  const int nchunks = p.cin_read >> 5;
+  const int ns = nchunks * 9;
+
+  auto load_b = [&](int t, int cc, int slot) {  // weight slice of (tap t, chunk cc)
+    const unsigned k0 = (unsigned)(t * p.cin_read + cc * 32);
+    char* sb = bring + slot * B_STAGE + wave * 1024;
+    if (wave < NBI)
+      __builtin_amdgcn_global_load_lds((glb_void*)(p.wt + w_src[0] + k0), (lds_void*)sb, 16, 0, 0);
+    if (wave + 4 < NBI)
+      __builtin_amdgcn_global_load_lds((glb_void*)(p.wt + w_src[1] + k0), (lds_void*)(sb + 4096), 16, 0, 0);
+  };
+  auto load_a = [&](int u, int cc, int buf) -> int {  // piece u of the patch of chunk cc
+    if (u * 4 + wave >= p.NI) return 0;
+    char* sa = lds + buf * patch_bytes + (u * 4 + wave) * 1024;
+    __builtin_amdgcn_global_load_lds((glb_void*)(p.in + a_src[u] + (unsigned)(cc * 32)), (lds_void*)sa, 16, 0, 0);
+    return 1;
+  };
+
+  // ---- fragment read addresses ---------------------------------------------
+  const int fr = lane & 15, fq = lane >> 4;
+  const int pjl = wm * 8 * p.SI + fr;          // + kh*SKH + kw + i*SI
+  const int b_rd = (wn * (BN / 2) + fr) * 64 + ((fq * 16) ^ ((fr & 4) << 3));
+
+  f32x4 acc[8][NREP];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < NREP; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: whole patch of chunk 0, weight slices of steps 0 and 1 -------
+#pragma unroll
+  for (int u = 0; u < 8; u++) load_a(u, 0, 0);
+  load_b(0, 0, 0);
+  int prev_cnt = 0;  // LDS-DMA instructions this wave issued in the previous step
+  if (ns > 1) {
+    load_b(1, 0, 1);
+    prev_cnt = nb_w;
+  }
+  if (dbg_t) t1 = clock64();
+
+  bf16x8 af[8], bfr[NREP];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) af[i][e] = (bf16)0.f;
+#pragma unroll
+  for (int j = 0; j < NREP; j++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) bfr[j][e] = (bf16)0.f;
+
+  int bslot = 0;
+  for (int cc = 0; cc < nchunks; cc++) {
+    const char* patch = lds + (cc & 1) * patch_bytes;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int s = cc * 9 + t;
+      long long ta = 0;
+      if (dbg_t) ta = clock64();
+      // everything issued before the previous step has landed
+      if (prev_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (prev_cnt == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (prev_cnt == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (dbg_t) tw += clock64() - ta;
+      // issue: weight slice of step s+2, piece t of the next chunk's patch
+      prev_cnt = 0;
+      if (s + 2 < ns && !(DBG && (p.debug & 2))) {
+        int t2n = t + 2, c2n = cc;
+        if (t2n >= 9) { t2n -= 9; c2n++; }
+        int sl = bslot + 2;
+        sl = sl >= NBS ? sl - NBS : sl;
+        load_b(t2n, c2n, sl);
+        prev_cnt = nb_w;
+      }
+      if (t < 8 && cc + 1 < nchunks && !(DBG && (p.debug & 1))) prev_cnt += load_a(t, cc + 1, (cc + 1) & 1);
+
+      // (the asm keeps the 72 (tap, i) read addresses from being hoisted out of the chunk loop
+      // into registers the accumulators need)
+      int pv = pjl;
+      asm volatile("" : "+v"(pv));
+      const int pj0 = pv + (t / 3) * p.SKH + (t % 3);
+      const char* bb = bring + bslot * B_STAGE + b_rd;
+      if constexpr (PIPE) {
+        // Software pipeline across the barrier: the fragments of step s are read here, right
+        // after the barrier that makes them visible, while the MFMAs issued in between are those
+        // of step s-1 (fragments already in registers); A fragment i is re-read into the
+        // registers the MFMAs of row block i have just consumed.  The first pass multiplies
+        // zero fragments.
+        bf16x8 bnx[NREP];
+#pragma unroll
+        for (int j = 0; j < NREP; j++) bnx[j] = *(const bf16x8*)(bb + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (!(DBG && (p.debug & 4))) {
+#pragma unroll
+            for (int j = 0; j < NREP; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          } else {
+            asm volatile("" ::"v"(af[i]));
+          }
+          const int pj = pj0 + i * p.SI;
+          af[i] = *(const bf16x8*)(patch + pj * 64 + ((fq * 16) ^ ((pj & 4) << 3)));
+        }
+        // pin the interleave (NREP MFMAs, one A-fragment read, ...): left alone the scheduler
+        // batches all reads behind all MFMAs and the next step starts with their latency exposed
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NREP, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NREP; j++) bfr[j] = bnx[j];
+      } else {
+        // all 8 + NREP fragment reads of the step are issued up front and the MFMAs wait for
+        // them one by one (counted lgkmcnt); the sched_barrier keeps the compiler from sinking
+        // the reads next to their uses
+#pragma unroll
+        for (int j = 0; j < NREP; j++) bfr[j] = *(const bf16x8*)(bb + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int pj = pj0 + i * p.SI;
+          af[i] = *(const bf16x8*)(patch + pj * 64 + ((fq * 16) ^ ((pj & 4) << 3)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG && (p.debug & 4))) {
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < NREP; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) asm volatile("" ::"v"(af[i]));
+        }
+      }
+      bslot = bslot + 1 == NBS ? 0 : bslot + 1;
+    }
+  }
+  if constexpr (PIPE) {  // MFMAs of the last step
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < NREP; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+  }
+  if (dbg_t) t2 = clock64();
+
+  // ---- epilogue --------------------------------------------------------------
+  // acc[i][j][e]: pixel row (wm*128 + i*16 + fr), channel (wn*BN/2 + j*16 + fq*4 + e)
+  const int cbase = wn * (BN / 2) + fq * 4;
+#pragma unroll
+  for (int j = 0; j < NREP; j++) {
+    const f32x4 bv = *(const f32x4*)(s_bias + cbase + j * 16);
+    f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.act == 2) sv = *(const f32x4*)(s_slope + cbase + j * 16);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float v = acc[i][j][e] + bv[e];
+        if (p.act) v = v > 0.f ? v : v * sv[e];
+        acc[i][j][e] = v;
+      }
+  }
+  __syncthreads();  // all fragment reads done, no LDS-DMA in flight (the last step waited for vmcnt(0))
+  // per output row: {batch index or -1, y << 16 | x} (interior coordinates)
+  int2* s_row = (int2*)bring;
+  {
+    const int Qc = Qc0 + (tid >> 4) * rowstep + (tid & 15);
+    const int HWp = Hp * Wp;
+    const int b = Qc / HWp;
+    const int rem = Qc - b * HWp;
+    const int yp = rem / Wp;
+    const int xp = rem - yp * Wp;
+    const bool ok = b < p.B && yp >= pi && yp < p.H + pi && xp >= pi && xp < p.W + pi;
+    s_row[tid] = make_int2(ok ? b : -1, ((yp - pi) << 16) | ((xp - pi) & 0xffff));
+  }
+  constexpr int VPR = BN / 8;
+  const int nvalid = p.cout - n0;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    if (half) __syncthreads();  // store reads of the first half are done
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < NREP; j++) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; e++) o[e] = (bf16)acc[i][j][e];
+          *(bf16x4*)(lds + (i * 16 + fr) * CROWB + (cbase + j * 16) * 2) = o;
+        }
+    }
+    __syncthreads();
+    for (int v = tid; v < 128 * VPR; v += NTHREADS) {
+      const int row = v / VPR;
+      const int cv = (v - row * VPR) * 8;
+      const int2 ri = s_row[half * 128 + row];
+      if (ri.x < 0 || cv >= nvalid) continue;
+      const int y = ri.y >> 16, x = ri.y & 0xffff;
+      const char* sp = lds + row * CROWB + cv * 2;
+      const u32x4 val = *(const u32x4*)sp;
+      for (int d = 0; d < p.n_dst; d++) {
+        const PhDst& ds = p.dst[d];
+        bf16* o = ds.base + (size_t)ds.org + ((size_t)(ri.x * ds.Hp + y) * ds.Wp + x) * ds.Cs + n0 + cv;
+        if (cv + 8 <= nvalid) {
+          *(u32x4*)o = val;
+        } else {
+          for (int e = 0; e < nvalid - cv; e++) o[e] = ((const bf16*)sp)[e];
+        }
+      }
+    }
+  }
+  if (dbg_t) {
+    __syncthreads();
+    if (tid == 0) {
+      const long long t3 = clock64();
+      atomicAdd(&ph_conv_dbg[0], (unsigned long long)(t1 - t0));
+      atomicAdd(&ph_conv_dbg[1], (unsigned long long)(t2 - t1));
+      atomicAdd(&ph_conv_dbg[2], (unsigned long long)(t3 - t2));
+      atomicAdd(&ph_conv_dbg[3], (unsigned long long)tw);
+      atomicAdd(&ph_conv_dbg[4], 1ull);
+    }
+  }
+}
+
+// Geometry of the halo kernel for one conv; returns false if the op does not fit it.
+bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
+  if (kh != 3 || p.KW != 3 || (p.cin_read & 31) || has_f32 || p.in_pad < 1 || p.n_dst < 1) return false;
+  const int Wp = p.in_Wp, Hp = p.in_Hp;
+  const int np_lin = 2 * (Wp < HALO_BM + 2 ? Wp : HALO_BM + 2) + HALO_BM + 2;
+  if (Wp < HALO_BM + 2 && (np_lin + 15) / 16 <= 32) {
+    p.halo_mode = 0;
+    p.q_first = p.in_pad * Wp + p.in_pad;
+    p.SKH = Wp;
+    p.SI = 16;
+    p.PR = Wp;
+    p.PCLIP = 2;
+    p.NI = (np_lin + 15) / 16;
+    const long long q_last = ((long long)(p.B - 1) * Hp + p.H - 1 + p.in_pad) * Wp + p.W - 1 + p.in_pad;
+    p.n_mtiles = (int)((q_last - p.q_first + HALO_BM) / HALO_BM);
+  } else {
+    p.halo_mode = 1;
+    p.tiles_x = (p.W + 15) / 16;
+    p.tiles_y = (p.H + 15) / 16;
+    p.SKH = 18;
+    p.SI = 18;
+    p.PR = 18;
+    p.PCLIP = 17;
+    p.NI = (18 * 18 + 15) / 16;
+    p.n_mtiles = p.B * p.tiles_x * p.tiles_y;
+  }
+  p.magic_pr = ph_magic(p.PR);
+  return true;
+}
+
+template <int NREP, bool DBG>
+static int launch_halo(const PhConvParams& p, hipStream_t stream) {
+  constexpr int BN = 32 * NREP;
+  const int ldsz = 2 * p.NI * 1024 + 3 * (BN / 16) * 1024 + 1024;
+  static int attr = 0;
+  if (attr < ldsz) {
+    PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<NREP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 ldsz));
+    attr = ldsz;
+  }
+  PhConvParams q = p;
+  q.n_ntiles = (p.cout + BN - 1) / BN;
+  hipLaunchKernelGGL((conv3x3_halo_kernel<NREP, DBG>), dim3(q.n_mtiles * q.n_ntiles), dim3(NTHREADS), ldsz, stream, q);
+  PH_CHECK(hipGetLastError());
+  return 0;
+}
+
 // variant 0: BK 64, 2 LDS stages, 2 blocks/CU.  variant 2 / 3: BK 32, 2 / 3 LDS stages, 4 / 3 blocks/CU.
+// variant 4: 3x3 halo-patch kernel (geometry from ph_conv_halo_plan).
 int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t stream) {
+  if (variant == 4) {
+    switch (nrep) {
+      case 1: return p.debug ? launch_halo<1, true>(p, stream) : launch_halo<1, false>(p, stream);
+      case 2: return p.debug ? launch_halo<2, true>(p, stream) : launch_halo<2, false>(p, stream);
+      case 3: return p.debug ? launch_halo<3, true>(p, stream) : launch_halo<3, false>(p, stream);
+      case 4: return p.debug ? launch_halo<4, true>(p, stream) : launch_halo<4, false>(p, stream);
+      default: ph_set_error("ph_launch_conv: bad nrep %d", nrep); return -1;
+    }
+  }
   if (variant == 2 || variant == 3) {
     switch (nrep * 10 + variant) {
       case 12: return launch_s<1, 2>(p, stream);

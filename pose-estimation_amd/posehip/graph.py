@@ -234,7 +234,8 @@ def build_plan(net, weights, height=None, width=None, tile_overrides=None):
         if n.kind == "concat" and n is not out:
             if not n.consumers:
                 continue
-            b = new_buf(sum(_r8(s.cout) for s in n.src), n.h, n.w)
+            # whole-buffer reads in 32-channel chunks (3x3 halo-patch kernel): pad the tail
+            b = new_buf((sum(_r8(s.cout) for s in n.src) + 31) // 32 * 32, n.h, n.w)
             off = 0
             lay = []
             for s in n.src:

@@ -78,7 +78,7 @@ def test_body25_plan_matches_survey_numbers():
     assert abs(plan.flops_per_frame() / 1e9 - 287.26) < 0.05            # ~287 GFLOP/frame
     assert plan.out_channels == 78 and (plan.in_h, plan.in_w) == (368, 656)
     widths = sorted({o["cin_read"] for o in plan.ops if o["type"] == _ffi.PH_OP_CONV})
-    assert widths == [8, 64, 96, 128, 184, 216, 256, 288, 384, 512]     # 3->8, 180->184, 206->216 (8-aligned members)
+    assert widths == [8, 64, 96, 128, 192, 224, 256, 288, 384, 512]     # 3->8; concat buffers: 8-aligned members, 32-aligned total
     for o in plan.ops:
         if o["type"] != _ffi.PH_OP_CONV:
             continue
