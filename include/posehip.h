@@ -60,6 +60,9 @@ typedef struct {
   int cin_caffe;            /* input channels of the Caffe weight blob */
   int slope_count;          /* 1 (channel_shared) or cout */
   int tile_n;               /* 0 = auto; else 32/64/96/128 */
+  int pool;                 /* 1: the Caffe 2x2 stride-2 MAX Pooling that follows is fused into the
+                               epilogue (3x3 convs, cin_read % 32 == 0, even H and W); the dst buffers
+                               then have the pooled geometry */
   const float* weight;      /* host [cout][cin_caffe][kh][kw] */
   const float* bias;        /* host [cout] or NULL */
   const float* slope;       /* host PReLU slopes or NULL */

@@ -290,9 +290,15 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
                    in.d.channels);
       return -1;
     }
+    if (d.pool && (d.kh != 3 || (d.cin_read & 31) || ((in.d.height | in.d.width) & 1) || d.f32_coff >= 0 ||
+                   d.n_dst < 1)) {
+      ph_set_error("ph_net_build: op %d: fused pooling needs a 3x3 conv, cin_read %% 32 == 0, even H and W", i);
+      return -1;
+    }
     for (int k = 0; k < d.n_dst; k++) {
       const Buf& ob = c->bufs[d.dst_buf[k]];
-      if (ob.d.height != in.d.height || ob.d.width != in.d.width || d.dst_coff[k] % 8 ||
+      const int oh = d.pool ? in.d.height / 2 : in.d.height, ow = d.pool ? in.d.width / 2 : in.d.width;
+      if (ob.d.height != oh || ob.d.width != ow || d.dst_coff[k] % 8 ||
           d.dst_coff[k] + d.cout > ob.d.channels) {
         ph_set_error("ph_net_build: op %d: dst %d geometry/channel window mismatch", i, k);
         return -1;
@@ -397,7 +403,15 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       const char* ev = getenv("POSEHIP_CONV_KERNEL");
       const int want = ev ? atoi(ev) : 4;
       o.variant = want;
-      if (want == 4 && !ph_conv_halo_plan(p, d.kh, d.f32_coff >= 0)) o.variant = 0;
+      p.pool = d.pool;
+      if (d.pool) o.variant = 4;  // only the halo kernel pools
+      if (o.variant == 4 && !ph_conv_halo_plan(p, d.kh, d.f32_coff >= 0)) {
+        if (d.pool) {
+          ph_set_error("ph_net_build: op %d: fused pooling not applicable", i);
+          return -1;
+        }
+        o.variant = 0;
+      }
     }
     int real_cin = 0;
     for (int cc = 0; cc < d.cin_read; cc++) real_cin += d.cin_map[cc] >= 0;

@@ -35,6 +35,7 @@ struct PhConvParams {
   int f32_C, f32_coff;
   int n_mtiles, n_ntiles;
   // 3x3 halo-patch kernel (conv3x3_halo_kernel) geometry, filled by ph_net_build
+  int pool;              // 1: 2x2/2 max pool fused into the epilogue (dst = pooled geometry), mode 1 only
   int in_pad, in_coff;   // border width of the input buffer, first channel of the read window
   int NQ;                // pixels of the padded input buffer (B * Hp * Wp)
   int halo_mode;         // 0: tiles are 256-pixel runs of the padded linear domain, 1: 16x16 pixel tiles

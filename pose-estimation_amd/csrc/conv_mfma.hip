@@ -568,17 +568,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
   const int Wp = p.in_Wp, Hp = p.in_Hp, pi = p.in_pad;
 
   // tile geometry: centre index of output row 0 / of the patch origin
-  int Qc0, rowstep;  // output row r = 16*i + px has centre Qc0 + i*rowstep + px
+  int Qc0;               // centre index of output row 0
+  int tb = 0, ty0 = 0, tx0 = 0;  // mode 1: image and origin of the 16x16 tile
   if (p.halo_mode == 0) {
     Qc0 = p.q_first + mt * HALO_BM;
-    rowstep = 16;
   } else {
     const int tx = mt % p.tiles_x;
     const int t2 = mt / p.tiles_x;
     const int ty = t2 % p.tiles_y;
-    const int b = t2 / p.tiles_y;
-    Qc0 = (b * Hp + ty * 16 + pi) * Wp + tx * 16 + pi;
-    rowstep = Wp;
+    tb = t2 / p.tiles_y;
+    ty0 = ty * 16;
+    tx0 = tx * 16;
+    Qc0 = (tb * Hp + ty0 + pi) * Wp + tx0 + pi;
   }
   const int Qbase = Qc0 - Wp - 1;
 
@@ -783,8 +784,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
   __syncthreads();  // all fragment reads done, no LDS-DMA in flight (the last step waited for vmcnt(0))
   // per output row: {batch index or -1, y << 16 | x} (interior coordinates)
   int2* s_row = (int2*)bring;
-  {
-    const int Qc = Qc0 + (tid >> 4) * rowstep + (tid & 15);
+  if (p.halo_mode == 0) {  // output row tid is padded-linear pixel Qc0 + tid: border pixels are dropped
+    const int Qc = Qc0 + tid;
     const int HWp = Hp * Wp;
     const int b = Qc / HWp;
     const int rem = Qc - b * HWp;
@@ -792,6 +793,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
     const int xp = rem - yp * Wp;
     const bool ok = b < p.B && yp >= pi && yp < p.H + pi && xp >= pi && xp < p.W + pi;
     s_row[tid] = make_int2(ok ? b : -1, ((yp - pi) << 16) | ((xp - pi) & 0xffff));
+  } else {                 // output row tid is pixel (tid >> 4, tid & 15) of the 16x16 tile
+    const int y = ty0 + (tid >> 4), x = tx0 + (tid & 15);
+    const bool ok = tb < p.B && y < p.H && x < p.W;
+    s_row[tid] = make_int2(ok ? tb : -1, (y << 16) | x);
   }
   constexpr int VPR = BN / 8;
   const int nvalid = p.cout - n0;
@@ -810,6 +815,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
         }
     }
     __syncthreads();
+    if (p.pool) {
+      // 2x2/2 max pool: this half holds tile rows 8*half .. 8*half+7 -> 4 x 8 pooled pixels
+      for (int v = tid; v < 32 * VPR; v += NTHREADS) {
+        const int prow = v / VPR;
+        const int cv = (v - prow * VPR) * 8;
+        const int r0 = (prow >> 3) * 32 + (prow & 7) * 2;
+        const int2 ri = s_row[half * 128 + r0];
+        if (ri.x < 0 || cv >= nvalid) continue;
+        const int y = ri.y >> 17, x = (ri.y & 0xffff) >> 1;
+        const char* sp = lds + r0 * CROWB + cv * 2;
+        const bf16x8 v00 = *(const bf16x8*)sp, v01 = *(const bf16x8*)(sp + CROWB);
+        const bf16x8 v10 = *(const bf16x8*)(sp + 16 * CROWB), v11 = *(const bf16x8*)(sp + 17 * CROWB);
+        bf16x8 mx;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          mx[e] = (bf16)fmaxf(fmaxf((float)v00[e], (float)v01[e]), fmaxf((float)v10[e], (float)v11[e]));
+        for (int d = 0; d < p.n_dst; d++) {
+          const PhDst& ds = p.dst[d];
+          bf16* o = ds.base + (size_t)ds.org + ((size_t)(ri.x * ds.Hp + y) * ds.Wp + x) * ds.Cs + n0 + cv;
+          if (cv + 8 <= nvalid) {
+            *(bf16x8*)o = mx;
+          } else {
+            for (int e = 0; e < nvalid - cv; e++) o[e] = mx[e];
+          }
+        }
+      }
+      continue;
+    }
     for (int v = tid; v < 128 * VPR; v += NTHREADS) {
       const int row = v / VPR;
       const int cv = (v - row * VPR) * 8;
@@ -847,7 +880,10 @@ bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
   if (kh != 3 || p.KW != 3 || (p.cin_read & 31) || has_f32 || p.in_pad < 1 || p.n_dst < 1) return false;
   const int Wp = p.in_Wp, Hp = p.in_Hp;
   const int np_lin = 2 * (Wp < HALO_BM + 2 ? Wp : HALO_BM + 2) + HALO_BM + 2;
-  if (Wp < HALO_BM + 2 && (np_lin + 15) / 16 <= 32) {
+  if (p.pool && ((p.H | p.W) & 1)) return false;
+  static const char* force = getenv("POSEHIP_HALO_MODE");  // tests: "1" forces the 16x16-tile form
+  const bool tiles2d = p.pool || (force && force[0] == '1');
+  if (!tiles2d && Wp < HALO_BM + 2 && (np_lin + 15) / 16 <= 32) {
     p.halo_mode = 0;
     p.q_first = p.in_pad * Wp + p.in_pad;
     p.SKH = Wp;

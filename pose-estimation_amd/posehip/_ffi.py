@@ -27,7 +27,7 @@ class PhOpDesc(C.Structure):
                 ("dst_buf", C.c_int * PH_MAX_DST),
                 ("dst_coff", C.c_int * PH_MAX_DST),
                 ("f32_coff", C.c_int), ("cin_caffe", C.c_int),
-                ("slope_count", C.c_int), ("tile_n", C.c_int),
+                ("slope_count", C.c_int), ("tile_n", C.c_int), ("pool", C.c_int),
                 ("weight", C.POINTER(C.c_float)),
                 ("bias", C.POINTER(C.c_float)),
                 ("slope", C.POINTER(C.c_float)),

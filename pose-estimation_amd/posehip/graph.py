@@ -16,6 +16,7 @@ Input: a parsed deploy prototxt (``caffe_io.parse_prototxt``) and a
   kernel's padding, so the kernels never mask.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -71,6 +72,7 @@ class Plan:
                 d.dst_buf[k], d.dst_coff[k] = b, c
             d.f32_coff = o["f32_coff"]
             d.tile_n = o.get("tile_n", 0)
+            d.pool = o.get("pool", 0)
             if o["type"] == _ffi.PH_OP_CONV:
                 w = np.ascontiguousarray(o["weight"], dtype=np.float32)
                 d.cin_caffe = w.shape[1]
@@ -199,7 +201,7 @@ def _build_nodes(net, height, width):
     return nodes, inp, last
 
 
-def build_plan(net, weights, height=None, width=None, tile_overrides=None):
+def build_plan(net, weights, height=None, width=None, tile_overrides=None, fuse_pool=True):
     """net: parsed prototxt; weights: {layer name: [blobs]}."""
     nodes, inp, out = _build_nodes(net, height, width)
     plan = Plan()
@@ -243,9 +245,21 @@ def build_plan(net, weights, height=None, width=None, tile_overrides=None):
                 lay.append((off, s.cout))
                 off += _r8(s.cout)
             concat_layout[n.name] = (b, lay)
+    # conv -> 2x2 max pool with nothing else reading the conv: the pool moves into the conv epilogue
+    # (the full-resolution blob is never written)
+    for n in nodes:
+        n.fused_pool = None
+    for n in nodes:
+        if n.kind == "pool" and fuse_pool and not os.environ.get("POSEHIP_NO_POOL_FUSION"):
+            c = n.src[0]
+            if (c.kind == "conv" and c.k == 3 and len(c.consumers) == 1 and not c.views and c.f32_coff < 0
+                    and c.h % 2 == 0 and c.w % 2 == 0 and _r8(c.src[0].cout) % 32 == 0
+                    and c.src[0].kind != "concat"):
+                c.fused_pool = n
+                n.kind = "fused_pool"
     # own buffers for blobs read directly that have no view yet
     for n in nodes:
-        if n.kind in ("conv", "pool") and not n.views:
+        if n.kind in ("conv", "pool", "fused_pool") and not n.views:
             if any(c.kind in ("conv", "pool") for c in n.consumers):
                 n.views = [(new_buf(n.cout, n.h, n.w), 0)]
 
@@ -283,11 +297,12 @@ def build_plan(net, weights, height=None, width=None, tile_overrides=None):
                 if n.act_name not in weights:
                     raise ValueError(f"no PReLU slopes for layer {n.act_name!r}")
                 slope = np.asarray(weights[n.act_name][0], np.float32).reshape(-1)
-            if len(n.views) > _ffi.PH_MAX_DST:
-                raise ValueError(f"layer {n.name!r} feeds {len(n.views)} buffers (max {_ffi.PH_MAX_DST})")
+            views = n.fused_pool.views if n.fused_pool is not None else n.views
+            if len(views) > _ffi.PH_MAX_DST:
+                raise ValueError(f"layer {n.name!r} feeds {len(views)} buffers (max {_ffi.PH_MAX_DST})")
             op = dict(type=_ffi.PH_OP_CONV, name=n.name, in_buf=b, in_coff=coff, cin_read=cr, k=n.k,
-                      cout=n.cout, act=n.act, dst=list(n.views), f32_coff=n.f32_coff, weight=w, bias=bias,
-                      slope=slope, cin_map=cmap, h=n.h, w=n.w)
+                      cout=n.cout, act=n.act, dst=list(views), f32_coff=n.f32_coff, weight=w, bias=bias,
+                      slope=slope, cin_map=cmap, h=n.h, w=n.w, pool=int(n.fused_pool is not None))
             if tile_overrides and n.name in tile_overrides:
                 op["tile_n"] = tile_overrides[n.name]
             plan.ops.append(op)

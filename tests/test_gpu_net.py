@@ -54,6 +54,9 @@ CASES = {
                                ("concat", "net_output", ["l1b", "l2"])]),
     "k7": (14, 18, [("conv", "f", "image", 64, 3, "ReLU"), ("conv", "g", "f", 128, 7, "ReLU"),
                      ("conv", "out", "g", 19, 1, None)]),
+    # width > 126: the 3x3 halo kernel switches from padded-linear runs to 16x16 tiles (ragged right/bottom tiles)
+    "wide_tiles": (18, 150, [("conv", "c1", "image", 32, 3, "ReLU"), ("conv", "c2", "c1", 64, 3, "PReLU"),
+                              ("conv", "c3", "c2", 96, 3, "ReLU"), ("conv", "out", "c3", 20, 1, None)]),
     "odd_pool": (13, 19, [("conv", "c1", "image", 64, 3, "ReLU"), ("pool", "p", "c1"),
                            ("conv", "out", "p", 38, 3, None)]),
 }
