@@ -95,10 +95,11 @@ def main():
     host_sc = torch.empty((B, MAX_PEOPLE), dtype=torch.float32).pin_memory()
 
     conv_ms_total = 0.0
+    op_ms_total = np.zeros(len(plan.ops))
     decode_ms = np.zeros(3)
 
     def step(timed):
-        nonlocal conv_ms_total, decode_ms
+        nonlocal conv_ms_total, decode_ms, op_ms_total
         eng.preprocess(frames, _ffi.PH_PRE_NATIVE)
         eng.forward_timed(B, wait=False)
         eng.decode_v2_dev(BODY_25, B, NET_H, NET_W, 1.0, MAX_PEOPLE)
@@ -113,6 +114,7 @@ def main():
         if timed:
             ms = eng.forward_times()
             conv_ms_total += float(ms[conv_mask].sum())
+            op_ms_total += ms
             decode_ms += np.array(eng.decode_v2_times())
 
     g = {}
@@ -154,6 +156,25 @@ def main():
         conv_s = conv_ms_total / 1e3
         achieved = flops_frame * B * args.steps / conv_s / 1e12 if conv_s > 0 else 0.0
         n_conv = int(conv_mask.sum())
+        # dominant kernel = the instantiation with the largest share of the timed region; its
+        # achieved rate = algorithmic FLOPs of its launches / their HIP-event durations
+        kernels = eng.op_kernels()
+        op_fl = eng.op_flops() * B
+        by_k = {}
+        for kname, t, f, c in zip(kernels, op_ms_total, op_fl, conv_mask):
+            if c:
+                a = by_k.setdefault(kname, [0.0, 0.0, 0])
+                a[0] += t
+                a[1] += f * args.steps
+                a[2] += args.steps
+        dom = max(by_k, key=lambda k: by_k[k][0])
+        d_ms, d_fl, d_n = by_k[dom]
+        d_ach = d_fl / (d_ms / 1e3) / 1e12 if d_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath):  # PMC passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE) of this same command
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("bytes_per_launch", {}).get(dom)
         line = {
             "metric": "frames/sec (BODY_25 368x656, full PAF decode)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -165,13 +186,19 @@ def main():
                                    "(BASELINE configs[1])",
                        "batch_per_gpu": B, "net_resolution": f"{NET_W}x{NET_H}", "weights": "random He-normal",
                        "parallelism": f"frame-parallel x{world}, RCCL keypoint all_gather"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_igemm_kernel (all instantiations)",
-                         "launches_per_step": n_conv,
-                         "avg_launch_ms": round(conv_ms_total / max(1, args.steps * n_conv), 4),
-                         "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
-                         "conv_ms_per_step": round(conv_ms_total / args.steps, 3),
+            "roofline": {"bound": "mfma", "achieved": round(d_ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(d_ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "kernel": dom,
+                         "launches_per_step": d_n // args.steps,
+                         "avg_launch_ms": round(d_ms / max(1, d_n), 4),
+                         "algorithmic_gflop_per_launch": round(d_fl / max(1, d_n) / 1e9, 2),
+                         "kernel_ms_per_step": round(d_ms / args.steps, 3),
+                         "all_conv": {"achieved": round(achieved, 2), "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                                      "launches_per_step": n_conv,
+                                      "conv_ms_per_step": round(conv_ms_total / args.steps, 3),
+                                      "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
+                                      "per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3)
+                                                                 for k, v in sorted(by_k.items())}},
                          "decode_ms_per_step": [round(float(x) / args.steps, 3) for x in decode_ms]},
         }
         if world == 1 and args.cpu_frames > 0:

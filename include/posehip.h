@@ -117,6 +117,9 @@ int ph_forward_timed(ph_ctx* ctx, int B, float* ms);
 int ph_forward_times(ph_ctx* ctx, float* ms);
 /* algorithmic FLOPs of op i for one frame (2*K*K*Cin*Cout*H*W, unpadded) */
 double ph_op_flops(ph_ctx* ctx, int op);
+/* name of the kernel instantiation op i launches (as rocprofv3 --kernel-trace prints it, without
+ * the argument list), e.g. "conv3x3_halo_kernel<4, false>"; measurement only, no reference counterpart */
+int ph_op_kernel(ph_ctx* ctx, int op, char* name, int cap);
 /* net output, fp32 NCHW [B][C][Hs][Ws] (what predict() returns, opencv/skeleton.py:75) */
 int ph_get_net_out(ph_ctx* ctx, int B, float* host_out);
 float* ph_net_out_dev(ph_ctx* ctx);

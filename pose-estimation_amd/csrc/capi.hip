@@ -513,6 +513,19 @@ double ph_op_flops(ph_ctx* c, int op) {
   return c->ops[op].flops;
 }
 
+int ph_op_kernel(ph_ctx* c, int op, char* name, int cap) {
+  if (op < 0 || op >= (int)c->ops.size() || !name || cap < 1) {
+    ph_set_error("ph_op_kernel: bad op %d", op);
+    return -1;
+  }
+  const Op& o = c->ops[op];
+  if (o.d.type == PH_OP_POOL) snprintf(name, cap, "maxpool2x2_kernel");
+  else if (o.variant == 4) snprintf(name, cap, "conv3x3_halo_kernel<%d, %s>", o.nrep, o.cp.debug ? "true" : "false");
+  else if (o.variant == 2 || o.variant == 3) snprintf(name, cap, "conv_igemm_s_kernel<%d, %d>", o.nrep, o.variant);
+  else snprintf(name, cap, "conv_igemm_kernel<%d>", o.nrep);
+  return 0;
+}
+
 int ph_get_net_out(ph_ctx* c, int B, float* host_out) {
   PH_CHECK(hipSetDevice(c->device));
   const size_t n = (size_t)B * c->cur_c * c->cur_h * c->cur_w;

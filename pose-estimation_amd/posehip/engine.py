@@ -83,6 +83,15 @@ class Engine:
     def op_flops(self):
         return np.array([max(0.0, self._lib.ph_op_flops(self._ctx, i)) for i in range(len(self.plan.ops))])
 
+    def op_kernels(self):
+        """Kernel instantiation name of every op (rocprofv3 kernel-trace spelling)."""
+        out = []
+        buf = C.create_string_buffer(128)
+        for i in range(len(self.plan.ops)):
+            _ffi.check(self._lib.ph_op_kernel(self._ctx, i, buf, 128), "ph_op_kernel")
+            out.append(buf.value.decode())
+        return out
+
     def net_out(self, B):
         p = self.plan
         out = np.empty((B, p.out_channels, p.out_h, p.out_w), np.float32)
