@@ -398,14 +398,16 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
     p.in_coff = d.in_coff;
     p.NQ = batch * in.Hp() * in.Wp();
     {
-      // kernel choice: POSEHIP_CONV_KERNEL=0/2/3 forces the im2col-gather kernels, default picks the
-      // 3x3 halo-patch kernel wherever it applies
+      // kernel choice: POSEHIP_CONV_KERNEL=0/2/3 forces the im2col-gather kernels, 4/5 the 3x3 halo-patch
+      // kernel (4 / 8 waves) wherever it applies
       const char* ev = getenv("POSEHIP_CONV_KERNEL");
-      const int want = ev ? atoi(ev) : 4;
+      // auto: halo kernel, 8-wave blocks below 128 output channels per tile (more waves hide the
+      // per-step latency there), 4-wave blocks with 128-row wave tiles at 128
+      const int want = ev ? atoi(ev) : (o.nrep <= 3 ? 5 : 4);
       o.variant = want;
       p.pool = d.pool;
-      if (d.pool) o.variant = 4;  // only the halo kernel pools
-      if (o.variant == 4 && !ph_conv_halo_plan(p, d.kh, d.f32_coff >= 0)) {
+      if (d.pool && want != 4 && want != 5) o.variant = 4;  // only the halo kernel pools
+      if ((o.variant == 4 || o.variant == 5) && !ph_conv_halo_plan(p, d.kh, d.f32_coff >= 0)) {
         if (d.pool) {
           ph_set_error("ph_net_build: op %d: fused pooling not applicable", i);
           return -1;
@@ -476,7 +478,7 @@ static int run_ops(ph_ctx* c, int B, bool timed) {
     } else {
       o.cp.B = B;
       o.cp.M = B * o.cp.H * o.cp.W;
-      if (o.variant == 4) ph_conv_halo_plan(o.cp, 3, false);  // tile count follows B
+      if (o.variant == 4 || o.variant == 5) ph_conv_halo_plan(o.cp, 3, false);  // tile count follows B
       if (ph_launch_conv(o.cp, o.nrep, o.variant, c->stream)) return -1;
     }
   }
@@ -520,7 +522,8 @@ int ph_op_kernel(ph_ctx* c, int op, char* name, int cap) {
   }
   const Op& o = c->ops[op];
   if (o.d.type == PH_OP_POOL) snprintf(name, cap, "maxpool2x2_kernel");
-  else if (o.variant == 4) snprintf(name, cap, "conv3x3_halo_kernel<%d, %s>", o.nrep, o.cp.debug ? "true" : "false");
+  else if (o.variant == 4 || o.variant == 5)
+    snprintf(name, cap, "conv3x3_halo_kernel<%d, %d, %s>", o.nrep, o.variant == 5 ? 4 : 2, o.cp.debug ? "true" : "false");
   else if (o.variant == 2 || o.variant == 3) snprintf(name, cap, "conv_igemm_s_kernel<%d, %d>", o.nrep, o.variant);
   else snprintf(name, cap, "conv_igemm_kernel<%d>", o.nrep);
   return 0;

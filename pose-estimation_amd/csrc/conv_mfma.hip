@@ -536,10 +536,15 @@ static int launch_s(const PhConvParams& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------
 #define HALO_BM 256
 
-template <int NREP, bool DBG>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams p) {
+template <int NREP, int MW, bool DBG>  // MW waves along M x 2 along N
+__global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConvParams p) {
   constexpr int BN = 32 * NREP;
-  constexpr bool PIPE = NREP < 4;              // cross-step fragment prefetch (registers allow it below NREP 4)
+  constexpr int NW = 2 * MW;                   // waves per block
+  constexpr int NT = 64 * NW;
+  constexpr int IB = 16 / MW;                  // 16-pixel row blocks per wave
+  constexpr int NPC = 32 / NW;                 // patch pieces (one LDS-DMA instruction per wave each)
+  constexpr int NBW = (8 + NW - 1) / NW;       // weight staging instructions per wave per step (max)
+  constexpr bool PIPE = NREP < 4;              // cross-step fragment prefetch (where registers allow it)
   constexpr int NBI = BN / 16;                 // 16-row weight staging instructions per K step
   constexpr int B_STAGE = NBI * 1024;
   constexpr int NBS = 3;
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % MW, wn = wave / MW;
   const bool dbg_t = DBG && (p.debug & 8) != 0;
   long long t0 = 0, t1 = 0, t2 = 0, tw = 0;
   if (dbg_t) t0 = clock64();
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
 
-  {  // bias / slope -> LDS
+  if (wave < 4) {  // bias / slope -> LDS
     const float* src = (wave < 2 ? p.bias : p.slope) + n0 + (wave & 1) * 64 + lane;
     float* dst = (wave < 2 ? s_bias : s_slope) + (wave & 1) * 64;
     __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 4, 0, 0);
@@ -594,10 +599,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
 
   // ---- staging addresses -----------------------------------------------------
   const int lchunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);   // source k-chunk of this lane's slot
-  unsigned a_src[8];
+  unsigned a_src[NPC];
 #pragma unroll
-  for (int u = 0; u < 8; u++) {
-    int idx = u * 4 + wave;
+  for (int u = 0; u < NPC; u++) {
+    int idx = u * NW + wave;
     idx = idx < p.NI ? idx : p.NI - 1;
     const int j = idx * 16 + (lane >> 2);
     int jr = (int)ph_div((unsigned)j, p.magic_pr, (unsigned)p.PR);
@@ -606,14 +611,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
     Q = Q < 0 ? 0 : (Q < p.NQ ? Q : p.NQ - 1);
     a_src[u] = (unsigned)Q * (unsigned)p.in_Cs + (unsigned)(p.in_coff + lchunk * 8);
   }
-  unsigned w_src[2];
+  unsigned w_src[NBW];
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
-    int n = n0 + (wave + i * 4) * 16 + (lane >> 2);
+  for (int i = 0; i < NBW; i++) {
+    int n = n0 + (wave + i * NW) * 16 + (lane >> 2);
     n = n < p.cout_pad ? n : p.cout_pad - 1;
     w_src[i] = (unsigned)n * (unsigned)p.Kpad + (unsigned)(lchunk * 8);
   }
-  const int nb_w = (wave < NBI ? 1 : 0) + (wave + 4 < NBI ? 1 : 0);  // weight instructions of this wave per step
+  int nb_w = 0;  // weight instructions of this wave per step
+#pragma unroll
+  for (int i = 0; i < NBW; i++) nb_w += wave + i * NW < NBI ? 1 : 0;
 
   const int nchunks = p.cin_read >> 5;
   const int ns = nchunks * 9;
@@ -621,32 +628,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
   auto load_b = [&](int t, int cc, int slot) {  // weight slice of (tap t, chunk cc)
     const unsigned k0 = (unsigned)(t * p.cin_read + cc * 32);
     char* sb = bring + slot * B_STAGE + wave * 1024;
-    if (wave < NBI)
-      __builtin_amdgcn_global_load_lds((glb_void*)(p.wt + w_src[0] + k0), (lds_void*)sb, 16, 0, 0);
-    if (wave + 4 < NBI)
-      __builtin_amdgcn_global_load_lds((glb_void*)(p.wt + w_src[1] + k0), (lds_void*)(sb + 4096), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NBW; i++)
+      if (wave + i * NW < NBI)
+        __builtin_amdgcn_global_load_lds((glb_void*)(p.wt + w_src[i] + k0), (lds_void*)(sb + i * NW * 1024), 16, 0, 0);
   };
   auto load_a = [&](int u, int cc, int buf) -> int {  // piece u of the patch of chunk cc
-    if (u * 4 + wave >= p.NI) return 0;
-    char* sa = lds + buf * patch_bytes + (u * 4 + wave) * 1024;
+    if (u * NW + wave >= p.NI) return 0;
+    char* sa = lds + buf * patch_bytes + (u * NW + wave) * 1024;
     __builtin_amdgcn_global_load_lds((glb_void*)(p.in + a_src[u] + (unsigned)(cc * 32)), (lds_void*)sa, 16, 0, 0);
     return 1;
   };
 
   // ---- fragment read addresses ---------------------------------------------
   const int fr = lane & 15, fq = lane >> 4;
-  const int pjl = wm * 8 * p.SI + fr;          // + kh*SKH + kw + i*SI
+  const int pjl = wm * IB * p.SI + fr;          // + kh*SKH + kw + i*SI
   const int b_rd = (wn * (BN / 2) + fr) * 64 + ((fq * 16) ^ ((fr & 4) << 3));
 
-  f32x4 acc[8][NREP];
+  f32x4 acc[IB][NREP];
 #pragma unroll
-  for (int i = 0; i < 8; i++)
+  for (int i = 0; i < IB; i++)
 #pragma unroll
     for (int j = 0; j < NREP; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: whole patch of chunk 0, weight slices of steps 0 and 1 -------
 #pragma unroll
-  for (int u = 0; u < 8; u++) load_a(u, 0, 0);
+  for (int u = 0; u < NPC; u++) load_a(u, 0, 0);
   load_b(0, 0, 0);
   int prev_cnt = 0;  // LDS-DMA instructions this wave issued in the previous step
   if (ns > 1) {
@@ -655,9 +662,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
   }
   if (dbg_t) t1 = clock64();
 
-  bf16x8 af[8], bfr[NREP];
+  bf16x8 af[IB], bfr[NREP];
 #pragma unroll
-  for (int i = 0; i < 8; i++)
+  for (int i = 0; i < IB; i++)
 #pragma unroll
     for (int e = 0; e < 8; e++) af[i][e] = (bf16)0.f;
 #pragma unroll
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
         load_b(t2n, c2n, sl);
         prev_cnt = nb_w;
       }
-      if (t < 8 && cc + 1 < nchunks && !(DBG && (p.debug & 1))) prev_cnt += load_a(t, cc + 1, (cc + 1) & 1);
+      if (t < NPC && cc + 1 < nchunks && !(DBG && (p.debug & 1))) prev_cnt += load_a(t, cc + 1, (cc + 1) & 1);
 
       // (the asm keeps the 72 (tap, i) read addresses from being hoisted out of the chunk loop
       // into registers the accumulators need)
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
 #pragma unroll
         for (int j = 0; j < NREP; j++) bnx[j] = *(const bf16x8*)(bb + j * 1024);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < IB; i++) {
           if (!(DBG && (p.debug & 4))) {
 #pragma unroll
             for (int j = 0; j < NREP; j++)
@@ -723,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
         // pin the interleave (NREP MFMAs, one A-fragment read, ...): left alone the scheduler
         // batches all reads behind all MFMAs and the next step starts with their latency exposed
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < IB; i++) {
           __builtin_amdgcn_sched_group_barrier(0x008, NREP, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -736,20 +743,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
 #pragma unroll
         for (int j = 0; j < NREP; j++) bfr[j] = *(const bf16x8*)(bb + j * 1024);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < IB; i++) {
           const int pj = pj0 + i * p.SI;
           af[i] = *(const bf16x8*)(patch + pj * 64 + ((fq * 16) ^ ((pj & 4) << 3)));
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!(DBG && (p.debug & 4))) {
 #pragma unroll
-          for (int i = 0; i < 8; i++)
+          for (int i = 0; i < IB; i++)
 #pragma unroll
             for (int j = 0; j < NREP; j++)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; i++) asm volatile("" ::"v"(af[i]));
+          for (int i = 0; i < IB; i++) asm volatile("" ::"v"(af[i]));
         }
       }
       bslot = bslot + 1 == NBS ? 0 : bslot + 1;
@@ -757,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
   }
   if constexpr (PIPE) {  // MFMAs of the last step
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < IB; i++)
 #pragma unroll
       for (int j = 0; j < NREP; j++)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
   if (dbg_t) t2 = clock64();
 
   // ---- epilogue --------------------------------------------------------------
-  // acc[i][j][e]: pixel row (wm*128 + i*16 + fr), channel (wn*BN/2 + j*16 + fq*4 + e)
+  // acc[i][j][e]: pixel row (wm*IB*16 + i*16 + fr), channel (wn*BN/2 + j*16 + fq*4 + e)
   const int cbase = wn * (BN / 2) + fq * 4;
 #pragma unroll
   for (int j = 0; j < NREP; j++) {
@@ -773,7 +780,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
     f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.act == 2) sv = *(const f32x4*)(s_slope + cbase + j * 16);
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < IB; i++)
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         float v = acc[i][j][e] + bv[e];
@@ -784,7 +791,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
   __syncthreads();  // all fragment reads done, no LDS-DMA in flight (the last step waited for vmcnt(0))
   // per output row: {batch index or -1, y << 16 | x} (interior coordinates)
   int2* s_row = (int2*)bring;
-  if (p.halo_mode == 0) {  // output row tid is padded-linear pixel Qc0 + tid: border pixels are dropped
+  if (tid >= HALO_BM) {
+  } else if (p.halo_mode == 0) {  // output row tid is padded-linear pixel Qc0 + tid: border pixels are dropped
     const int Qc = Qc0 + tid;
     const int HWp = Hp * Wp;
     const int b = Qc / HWp;
@@ -803,21 +811,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     if (half) __syncthreads();  // store reads of the first half are done
-    if (wm == half) {
+    if (wm / (MW / 2) == half) {
 #pragma unroll
-      for (int i = 0; i < 8; i++)
+      for (int i = 0; i < IB; i++)
 #pragma unroll
         for (int j = 0; j < NREP; j++) {
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; e++) o[e] = (bf16)acc[i][j][e];
-          *(bf16x4*)(lds + (i * 16 + fr) * CROWB + (cbase + j * 16) * 2) = o;
+          *(bf16x4*)(lds + ((wm % (MW / 2)) * IB * 16 + i * 16 + fr) * CROWB + (cbase + j * 16) * 2) = o;
         }
     }
     __syncthreads();
     if (p.pool) {
       // 2x2/2 max pool: this half holds tile rows 8*half .. 8*half+7 -> 4 x 8 pooled pixels
-      for (int v = tid; v < 32 * VPR; v += NTHREADS) {
+      for (int v = tid; v < 32 * VPR; v += NT) {
         const int prow = v / VPR;
         const int cv = (v - prow * VPR) * 8;
         const int r0 = (prow >> 3) * 32 + (prow & 7) * 2;
@@ -843,7 +851,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const PhConvParams
       }
       continue;
     }
-    for (int v = tid; v < 128 * VPR; v += NTHREADS) {
+    for (int v = tid; v < 128 * VPR; v += NT) {
       const int row = v / VPR;
       const int cv = (v - row * VPR) * 8;
       const int2 ri = s_row[half * 128 + row];
@@ -908,32 +916,40 @@ bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
   return true;
 }
 
-template <int NREP, bool DBG>
+template <int NREP, int MW, bool DBG>
 static int launch_halo(const PhConvParams& p, hipStream_t stream) {
   constexpr int BN = 32 * NREP;
   const int ldsz = 2 * p.NI * 1024 + 3 * (BN / 16) * 1024 + 1024;
   static int attr = 0;
   if (attr < ldsz) {
-    PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<NREP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 ldsz));
+    PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<NREP, MW, DBG>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, ldsz));
     attr = ldsz;
   }
   PhConvParams q = p;
   q.n_ntiles = (p.cout + BN - 1) / BN;
-  hipLaunchKernelGGL((conv3x3_halo_kernel<NREP, DBG>), dim3(q.n_mtiles * q.n_ntiles), dim3(NTHREADS), ldsz, stream, q);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<NREP, MW, DBG>), dim3(q.n_mtiles * q.n_ntiles), dim3(128 * MW), ldsz, stream,
+                     q);
   PH_CHECK(hipGetLastError());
   return 0;
+}
+
+template <int NREP>
+static int launch_halo_sel(const PhConvParams& p, int mw, hipStream_t stream) {
+  if (mw == 4) return p.debug ? launch_halo<NREP, 4, true>(p, stream) : launch_halo<NREP, 4, false>(p, stream);
+  return p.debug ? launch_halo<NREP, 2, true>(p, stream) : launch_halo<NREP, 2, false>(p, stream);
 }
 
 // variant 0: BK 64, 2 LDS stages, 2 blocks/CU.  variant 2 / 3: BK 32, 2 / 3 LDS stages, 4 / 3 blocks/CU.
 // variant 4: 3x3 halo-patch kernel (geometry from ph_conv_halo_plan).
 int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t stream) {
-  if (variant == 4) {
+  if (variant == 4 || variant == 5) {  // 5: 8-wave blocks
+    const int mw = variant == 5 ? 4 : 2;
     switch (nrep) {
-      case 1: return p.debug ? launch_halo<1, true>(p, stream) : launch_halo<1, false>(p, stream);
-      case 2: return p.debug ? launch_halo<2, true>(p, stream) : launch_halo<2, false>(p, stream);
-      case 3: return p.debug ? launch_halo<3, true>(p, stream) : launch_halo<3, false>(p, stream);
-      case 4: return p.debug ? launch_halo<4, true>(p, stream) : launch_halo<4, false>(p, stream);
+      case 1: return launch_halo_sel<1>(p, mw, stream);
+      case 2: return launch_halo_sel<2>(p, mw, stream);
+      case 3: return launch_halo_sel<3>(p, mw, stream);
+      case 4: return launch_halo_sel<4>(p, mw, stream);
       default: ph_set_error("ph_launch_conv: bad nrep %d", nrep); return -1;
     }
   }
