@@ -609,14 +609,14 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     jr = jr < p.PCLIP ? jr : p.PCLIP;
     int Q = Qbase + j + jr * (Wp - p.PR);
     Q = Q < 0 ? 0 : (Q < p.NQ ? Q : p.NQ - 1);
-    a_src[u] = (unsigned)Q * (unsigned)p.in_Cs + (unsigned)(p.in_coff + lchunk * 8);
+    a_src[u] = ((unsigned)Q * (unsigned)p.in_Cs + (unsigned)(p.in_coff + lchunk * 8)) * 2u;  // BYTE offset
   }
   unsigned w_src[NBW];
 #pragma unroll
   for (int i = 0; i < NBW; i++) {
     int n = n0 + (wave + i * NW) * 16 + (lane >> 2);
     n = n < p.cout_pad ? n : p.cout_pad - 1;
-    w_src[i] = (unsigned)n * (unsigned)p.Kpad + (unsigned)(lchunk * 8);
+    w_src[i] = ((unsigned)n * (unsigned)p.Kpad + (unsigned)(lchunk * 8)) * 2u;  // BYTE offset
   }
   int nb_w = 0;  // weight instructions of this wave per step
 #pragma unroll
@@ -626,17 +626,19 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   const int ns = nchunks * 9;
 
   auto load_b = [&](int t, int cc, int slot) {  // weight slice of (tap t, chunk cc)
-    const unsigned k0 = (unsigned)(t * p.cin_read + cc * 32);
+    const unsigned k0 = (unsigned)(t * p.cin_read + cc * 32) * 2u;
+    const char* wbase = (const char*)p.wt;  // uniform base + 32-bit lane offset: saddr addressing, no 64-bit VGPR pairs
     char* sb = bring + slot * B_STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < NBW; i++)
       if (wave + i * NW < NBI)
-        __builtin_amdgcn_global_load_lds((glb_void*)(p.wt + w_src[i] + k0), (lds_void*)(sb + i * NW * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(wbase + (w_src[i] + k0)), (lds_void*)(sb + i * NW * 1024), 16, 0, 0);
   };
   auto load_a = [&](int u, int cc, int buf) -> int {  // piece u of the patch of chunk cc
     if (u * NW + wave >= p.NI) return 0;
     char* sa = lds + buf * patch_bytes + (u * NW + wave) * 1024;
-    __builtin_amdgcn_global_load_lds((glb_void*)(p.in + a_src[u] + (unsigned)(cc * 32)), (lds_void*)sa, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void*)((const char*)p.in + (a_src[u] + (unsigned)(cc * 64))), (lds_void*)sa, 16, 0,
+                                     0);
     return 1;
   };
 
@@ -886,6 +888,10 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 // Geometry of the halo kernel for one conv; returns false if the op does not fit it.
 bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
   if (kh != 3 || p.KW != 3 || (p.cin_read & 31) || has_f32 || p.in_pad < 1 || p.n_dst < 1) return false;
+  // the kernel addresses input and weights with 32-bit byte offsets
+  if ((unsigned long long)p.NQ * p.in_Cs * 2ull >= 0xffffffffull ||
+      (unsigned long long)p.cout_pad * p.Kpad * 2ull >= 0xffffffffull)
+    return false;
   const int Wp = p.in_Wp, Hp = p.in_Hp;
   const int np_lin = 2 * (Wp < HALO_BM + 2 ? Wp : HALO_BM + 2) + HALO_BM + 2;
   if (p.pool && ((p.H | p.W) & 1)) return false;
