@@ -9,6 +9,9 @@
   v1_scenes.npz        / V1 oracle's outputs for them (inputs + expected outputs;
                        produced by oracle/*.py, NOT by the reference, which cannot
                        run offline -- SURVEY 8c).
+  real_images.npz      G6: data/test/pillar_text.jpg and data/sample/COCO_val2014_000000000192.jpg
+                       decoded with PIL exactly as read_color_file does (utils_rs.py:43-44: RGB -> BGR),
+                       plus the oracle's cv2.resize restatement of each at 656x368 (data only).
   ref_predictions_native.txt  is a verbatim copy of the reference's only stored
                        result, data/test/output/inference_native/predictions.txt.
 """
@@ -57,6 +60,18 @@ def v2():
     np.savez_compressed(os.path.join(HERE, "v2_scenes.npz"), **out)
 
 
+def real_images():
+    from PIL import Image
+    from oracle import preprocess
+    out = {}
+    for tag, path in (("pillar_text", "/root/reference/data/test/pillar_text.jpg"),
+                      ("coco_192", "/root/reference/data/sample/COCO_val2014_000000000192.jpg")):
+        bgr = np.array(Image.open(path))[:, :, ::-1].copy()
+        out[tag + "_bgr"] = bgr
+        out[tag + "_resized_656x368"] = preprocess.cv_resize_u8(bgr[None], 656, 368)[0]
+    np.savez_compressed(os.path.join(HERE, "real_images.npz"), **out)
+
+
 def v1():
     from oracle import decode_v1
     from posehip import synth
@@ -79,4 +94,5 @@ if __name__ == "__main__":
     tables()
     v2()
     v1()
+    real_images()
     print("golden fixtures written to", HERE)

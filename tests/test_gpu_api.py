@@ -154,7 +154,8 @@ def test_preprocess_modes_match_restated_cv2(engine):
     big = synth.synth_frames(5, 2, 51, 77)
     engine.preprocess(big, _ffi.PH_PRE_CV2)
     got = engine.get_buffer(0)[:, 1:-1, 1:-1, :3]
-    ref = _cv_resize_u8(big, 40, 24).astype(np.float32) * np.float32(1 / 255.0)
+    from oracle import preprocess as pre_ref
+    ref = pre_ref.cv_resize_u8(big, 40, 24).astype(np.float32) * np.float32(1 / 255.0)
     ref16 = ((ref.view(np.uint32) + 0x7fff + ((ref.view(np.uint32) >> 16) & 1)) >> 16 << 16).astype(np.uint32)
     np.testing.assert_array_equal(got.view(np.uint32), ref16)
     engine.preprocess(big, _ffi.PH_PRE_NATIVE)                       # keep-aspect, x/256-0.5, zero fill -> -0.5
@@ -164,26 +165,19 @@ def test_preprocess_modes_match_restated_cv2(engine):
     assert (nat[:, :, int(77 * s) + 2:] == -0.5).all()               # right of the scaled image: filled with 0 -> -0.5
 
 
-def _cv_resize_u8(img, W, H):
-    """OpenCV 4.5 resize INTER_LINEAR on uint8 (11-bit fixed point), restated."""
-    B, H0, W0, _ = img.shape
-    def coords(n_dst, n_src, clamp_reset):
-        d = np.arange(n_dst, dtype=np.float64)
-        f = ((d + 0.5) * (n_src / n_dst) - 0.5).astype(np.float32)
-        s = np.floor(f).astype(np.int32)
-        f = (f - s).astype(np.float32)
-        if clamp_reset:
-            lo, hi = s < 0, s >= n_src - 1
-            f[lo] = 0; s[lo] = 0; f[hi] = 0; s[hi] = n_src - 1
-        c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int32)
-        c1 = np.rint(f * np.float32(2048)).astype(np.int32)
-        return s, c0, c1
-    sx, a0, a1 = coords(W, W0, True)
-    sy, b0, b1 = coords(H, H0, False)
-    sx1 = np.minimum(sx + 1, W0 - 1)
-    sy0, sy1 = np.clip(sy, 0, H0 - 1), np.clip(sy + 1, 0, H0 - 1)
-    im = img.astype(np.int32)
-    rows = im[:, :, sx] * a0[None, None, :, None] + im[:, :, sx1] * a1[None, None, :, None]
-    S0, S1 = rows[:, sy0], rows[:, sy1]
-    d = (((b0[None, :, None, None] * (S0 >> 4)) >> 16) + ((b1[None, :, None, None] * (S1 >> 4)) >> 16) + 2) >> 2
-    return np.clip(d, 0, 255).astype(np.uint8)
+def test_real_images_preprocess_matches_golden(engine):
+    """G6: the reference's own JPEGs (decoded with PIL as read_color_file does, utils_rs.py:43-44)
+    through the blobFromImage restatement -- committed inputs + expected u8 resize, GPU bit-exact."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "real_images.npz"))
+    net = caffe_io.parse_prototxt('input: "image" input_dim: 1 input_dim: 3 input_dim: 368 input_dim: 656\n' +
+                                  caffe_io._conv("out", "image", 8, 3))
+    plan = graph.build_plan(net, graph.random_weights(net, 0))
+    engine.build(plan, 1)
+    for tag in ("pillar_text", "coco_192"):
+        img, want_u8 = g[tag + "_bgr"], g[tag + "_resized_656x368"]
+        engine.preprocess(img[None], _ffi.PH_PRE_CV2)
+        got = engine.get_buffer(0)[:, 1:-1, 1:-1, :3]
+        ref = want_u8[None].astype(np.float32) * np.float32(1 / 255.0)
+        ref16 = ((ref.view(np.uint32) + 0x7fff + ((ref.view(np.uint32) >> 16) & 1)) >> 16 << 16).astype(np.uint32)
+        np.testing.assert_array_equal(got.view(np.uint32), ref16)

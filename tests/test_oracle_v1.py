@@ -132,3 +132,22 @@ def test_golden_scenes(tag):
     kl, people = decode_v1.postprocess_multi(pred, BP, PP, tables.MAPIDX, W, H, 0.1)
     np.testing.assert_array_equal(kl, g[tag + "_kl"])
     np.testing.assert_array_equal(np.stack(people) if people else np.zeros((0, 19)), g[tag + "_people"])
+
+
+def test_preprocess_restatement_known_answers_and_fixture():
+    """K1 oracle (cv2.resize INTER_LINEAR u8, 11-bit fixed point): hand-computed cases + the G6 fixture."""
+    import os
+    from oracle import preprocess
+    img = np.array([[[0, 0, 0], [255, 255, 255]]], np.uint8)[None]           # 1x2 -> 1x4
+    np.testing.assert_array_equal(preprocess.cv_resize_u8(img, 4, 1)[0, 0, :, 0], [0, 64, 191, 255])
+    same = np.arange(2 * 5 * 7 * 3, dtype=np.uint8).reshape(2, 5, 7, 3)
+    np.testing.assert_array_equal(preprocess.cv_resize_u8(same, 7, 5), same)  # same size: identity
+    flat = np.full((1, 9, 11, 3), 137, np.uint8)
+    assert (preprocess.cv_resize_u8(flat, 40, 24) == 137).all()               # weights sum to 2048: constants survive
+    blob = preprocess.blob_from_image(flat, 8, 8)
+    assert blob.shape == (1, 3, 8, 8) and blob.dtype == np.float32
+    np.testing.assert_array_equal(blob, np.float32(137) * np.float32(1 / 255.0))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "real_images.npz"))
+    for tag in ("pillar_text", "coco_192"):
+        got = preprocess.cv_resize_u8(g[tag + "_bgr"][None], 656, 368)[0]
+        np.testing.assert_array_equal(got, g[tag + "_resized_656x368"])
