@@ -50,6 +50,7 @@ struct Op {
   float* bias = nullptr;
   float* slope = nullptr;
   double flops = 0.0;  // algorithmic, per frame
+  bool skip = false;   // computed inside the next op's kernel (stem fusion)
 };
 
 struct ph_ctx {
@@ -424,6 +425,44 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
     o.d.slope = nullptr;
     o.d.cin_map = nullptr;
   }
+  // Stem fusion: a 3x3 conv over the 8-channel frame buffer (conv1_1) whose 64-channel output is read only
+  // by the next 3x3 conv (conv1_2) is computed inside that conv's kernel, straight into its LDS patch; the
+  // full-resolution 64-channel blob (1 GB at 32 x 368x656) is then never written or read.
+  if (!getenv("POSEHIP_NO_STEM_FUSION")) {
+    for (int i = 0; i + 1 < n_ops; i++) {
+      Op& a = c->ops[i];
+      Op& b = c->ops[i + 1];
+      if (a.d.type != PH_OP_CONV || b.d.type != PH_OP_CONV) continue;
+      const Buf& fb = c->bufs[a.d.in_buf];
+      if (a.d.kh != 3 || a.d.cin_read != 8 || a.d.in_coff != 0 || fb.d.channels != 8 || a.d.cout != 64 ||
+          a.d.act > PH_ACT_RELU || a.d.n_dst != 1 || a.d.f32_coff >= 0 || a.d.dst_coff[0] != 0 || a.d.pool)
+        continue;
+      if (b.d.kh != 3 || b.d.in_buf != a.d.dst_buf[0] || b.d.in_coff != 0 || b.d.cin_read != 64 || b.d.cout > 64 ||
+          b.nrep != 2 || (b.variant != 4 && b.variant != 5) || b.cp.debug)
+        continue;
+      bool shared = false;
+      for (int j = 0; j < n_ops; j++)
+        if (j != i + 1 && c->ops[j].d.in_buf == a.d.dst_buf[0]) shared = true;
+      if (shared) continue;
+      PhConvParams q = b.cp;
+      q.stem = 1;
+      q.wt0 = a.wt;
+      q.bias0 = a.bias;
+      q.Kpad0 = a.cp.Kpad;
+      q.act0 = a.d.act;
+      q.in = fb.ptr;
+      q.in_Hp = fb.Hp();
+      q.in_Wp = fb.Wp();
+      q.in_Cs = 8;
+      q.in_pad = fb.d.pad;
+      q.in_coff = 0;
+      q.NQ = batch * fb.Hp() * fb.Wp();
+      if (q.Kpad0 < 96 || !ph_conv_halo_plan(q, 3, false)) continue;
+      b.cp = q;
+      b.variant = 5;
+      a.skip = true;
+    }
+  }
   c->op_ev.resize(n_ops + 1);
   for (auto& e : c->op_ev) PH_CHECK(hipEventCreate(&e));
   c->cur_out = c->net_out;
@@ -469,6 +508,7 @@ static int run_ops(ph_ctx* c, int B, bool timed) {
     Op& o = c->ops[i];
     if (timed) PH_CHECK(hipEventRecord(c->op_ev[i], c->stream));
     const Buf& in = c->bufs[o.d.in_buf];
+    if (o.skip) continue;
     if (o.d.type == PH_OP_POOL) {
       const Buf& ob = c->bufs[o.d.dst_buf[0]];
       if (ph_launch_maxpool(in.ptr, ob.ptr, B, in.d.height, in.d.width, in.d.channels, in.Hp(), in.Wp(),
@@ -521,7 +561,9 @@ int ph_op_kernel(ph_ctx* c, int op, char* name, int cap) {
     return -1;
   }
   const Op& o = c->ops[op];
-  if (o.d.type == PH_OP_POOL) snprintf(name, cap, "maxpool2x2_kernel");
+  if (o.skip) snprintf(name, cap, "(fused into the next op)");
+  else if (o.d.type == PH_OP_POOL) snprintf(name, cap, "maxpool2x2_kernel");
+  else if (o.cp.stem) snprintf(name, cap, "conv3x3_halo_kernel<2, 4, false, true>");
   else if (o.variant == 4 || o.variant == 5)
     snprintf(name, cap, "conv3x3_halo_kernel<%d, %d, %s>", o.nrep, o.variant == 5 ? 4 : 2, o.cp.debug ? "true" : "false");
   else if (o.variant == 2 || o.variant == 3) snprintf(name, cap, "conv_igemm_s_kernel<%d, %d>", o.nrep, o.variant);

@@ -35,6 +35,13 @@ struct PhConvParams {
   int f32_C, f32_coff;
   int n_mtiles, n_ntiles;
   // 3x3 halo-patch kernel (conv3x3_halo_kernel) geometry, filled by ph_net_build
+  // stem fusion (conv3x3_halo_kernel<.., STEM>): the PRODUCER of this conv's input is a 3x3 conv over an
+  // 8-channel buffer (conv1_1); its output patch is computed in LDS instead of being read.  `in`, in_Hp,
+  // in_Wp, in_pad, NQ then describe the 8-channel buffer.
+  int stem;
+  const bf16* wt0;       // [64][Kpad0] producer weights, k = tap*8 + c
+  const float* bias0;    // [64]
+  int Kpad0, act0;       // act0: 0 none, 1 ReLU
   int pool;              // 1: 2x2/2 max pool fused into the epilogue (dst = pooled geometry), mode 1 only
   int in_pad, in_coff;   // border width of the input buffer, first channel of the read window
   int NQ;                // pixels of the padded input buffer (B * Hp * Wp)

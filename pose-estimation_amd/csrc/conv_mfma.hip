@@ -536,7 +536,7 @@ static int launch_s(const PhConvParams& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------
 #define HALO_BM 256
 
-template <int NREP, int MW, bool DBG>  // MW waves along M x 2 along N
+template <int NREP, int MW, bool DBG, bool STEM = false>  // MW waves along M x 2 along N
 __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConvParams p) {
   constexpr int BN = 32 * NREP;
   constexpr int NW = 2 * MW;                   // waves per block
@@ -554,6 +554,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   char* const bring = lds + 2 * patch_bytes;
   float* const s_bias = (float*)(bring + NBS * B_STAGE);
   float* const s_slope = s_bias + 128;
+  char* const s_in = (char*)(s_slope + 128);   // STEM: 20x20 pixel x 16 B input patch of the producer conv
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -654,13 +655,78 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     for (int j = 0; j < NREP; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: whole patch of chunk 0, weight slices of steps 0 and 1 -------
+  if constexpr (!STEM) {
 #pragma unroll
-  for (int u = 0; u < NPC; u++) load_a(u, 0, 0);
+    for (int u = 0; u < NPC; u++) load_a(u, 0, 0);
+  }
   load_b(0, 0, 0);
   int prev_cnt = 0;  // LDS-DMA instructions this wave issued in the previous step
   if (ns > 1) {
     load_b(1, 0, 1);
     prev_cnt = nb_w;
+  }
+  if constexpr (STEM) {
+    // ---- stem: this conv's 18x18 x 64-channel input patch = ReLU(conv3x3(8-channel frame patch)) ----
+    // 20x20 frame pixels (16 B each) -> s_in; border pixels of the 18x18 patch that fall outside the
+    // image are this conv's zero padding, so whatever the clamped loads bring for them is masked below
+    static_assert(!STEM || (NREP == 2 && MW == 4), "stem fusion is built for 64 -> 64 channels, 8 waves");
+    if (wave < 7) {
+      int jj = wave * 64 + lane;
+      jj = jj < 400 ? jj : 399;
+      const int rr = jj / 20, c2 = jj - rr * 20;
+      int Q = (tb * Hp + ty0 - 2 + rr + pi) * Wp + tx0 - 2 + c2 + pi;
+      Q = Q < 0 ? 0 : (Q < p.NQ ? Q : p.NQ - 1);
+      __builtin_amdgcn_global_load_lds((glb_void*)((const char*)p.in + (unsigned)Q * 16u), (lds_void*)(s_in + wave * 1024),
+                                       16, 0, 0);
+    }
+    const int lf = lane & 15, lq = lane >> 4;
+    bf16x8 wf[4][3];
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+      for (int ks = 0; ks < 3; ks++)
+        wf[nb][ks] = *(const bf16x8*)(p.wt0 + (nb * 16 + lf) * p.Kpad0 + ks * 32 + lq * 8);
+    f32x4 b0[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) b0[nb] = *(const f32x4*)(p.bias0 + nb * 16 + lq * 4);
+    int toff[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++) {
+      int t = ks * 4 + lq;
+      t = t < 8 ? t : 8;  // taps 9..11 carry zero weights: read any finite pixel
+      toff[ks] = ((t / 3) * 20 + (t % 3)) * 16;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    prev_cnt = 0;  // everything issued so far has landed
+    for (int rb = wave; rb < 21; rb += NW) {
+      const int j = rb * 16 + lf;
+      const int jc = j < 324 ? j : 323;
+      const int r = jc / 18, c = jc - r * 18;
+      const char* src = s_in + (r * 20 + c) * 16;
+      bf16x8 xf[3];
+#pragma unroll
+      for (int ks = 0; ks < 3; ks++) xf[ks] = *(const bf16x8*)(src + toff[ks]);
+      const int y = ty0 - 1 + r, x = tx0 - 1 + c;
+      const bool inside = j < 324 && tb < p.B && y >= 0 && y < p.H && x >= 0 && x < p.W;
+#pragma unroll
+      for (int nb = 0; nb < 4; nb++) {
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], xf[ks], a0, 0, 0, 0);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float v = a0[e] + b0[nb][e];
+          if (p.act0) v = v > 0.f ? v : 0.f;
+          o[e] = (bf16)(inside ? v : 0.f);
+        }
+        // channel nb*16 + lq*4 + e of patch pixel j: chunk nb >> 1, 16-B slot (nb & 1)*2 + (lq >> 1), swizzled
+        const int slot = ((nb & 1) * 2 + (lq >> 1)) ^ (((j >> 2) & 1) << 1);
+        *(bf16x4*)(lds + (nb >> 1) * patch_bytes + j * 64 + slot * 16 + (lq & 1) * 8) = o;
+      }
+    }
+    // (the first K step's barrier makes the patch visible to every wave)
   }
   if (dbg_t) t1 = clock64();
 
@@ -700,7 +766,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         load_b(t2n, c2n, sl);
         prev_cnt = nb_w;
       }
-      if (t < NPC && cc + 1 < nchunks && !(DBG && (p.debug & 1))) prev_cnt += load_a(t, cc + 1, (cc + 1) & 1);
+      if (!STEM && t < NPC && cc + 1 < nchunks && !(DBG && (p.debug & 1))) prev_cnt += load_a(t, cc + 1, (cc + 1) & 1);
 
       // (the asm keeps the 72 (tap, i) read addresses from being hoisted out of the chunk loop
       // into registers the accumulators need)
@@ -896,7 +962,7 @@ bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
   const int np_lin = 2 * (Wp < HALO_BM + 2 ? Wp : HALO_BM + 2) + HALO_BM + 2;
   if (p.pool && ((p.H | p.W) & 1)) return false;
   static const char* force = getenv("POSEHIP_HALO_MODE");  // tests: "1" forces the 16x16-tile form
-  const bool tiles2d = p.pool || (force && force[0] == '1');
+  const bool tiles2d = p.pool || p.stem || (force && force[0] == '1');
   if (!tiles2d && Wp < HALO_BM + 2 && (np_lin + 15) / 16 <= 32) {
     p.halo_mode = 0;
     p.q_first = p.in_pad * Wp + p.in_pad;
@@ -940,6 +1006,21 @@ static int launch_halo(const PhConvParams& p, hipStream_t stream) {
   return 0;
 }
 
+static int launch_halo_stem(const PhConvParams& p, hipStream_t stream) {
+  const int ldsz = 2 * p.NI * 1024 + 3 * 4 * 1024 + 1024 + 7 * 1024;
+  static bool attr = false;
+  if (!attr) {
+    PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<2, 4, false, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, ldsz));
+    attr = true;
+  }
+  PhConvParams q = p;
+  q.n_ntiles = 1;
+  hipLaunchKernelGGL((conv3x3_halo_kernel<2, 4, false, true>), dim3(q.n_mtiles), dim3(512), ldsz, stream, q);
+  PH_CHECK(hipGetLastError());
+  return 0;
+}
+
 template <int NREP>
 static int launch_halo_sel(const PhConvParams& p, int mw, hipStream_t stream) {
   if (mw == 4) return p.debug ? launch_halo<NREP, 4, true>(p, stream) : launch_halo<NREP, 4, false>(p, stream);
@@ -949,6 +1030,7 @@ static int launch_halo_sel(const PhConvParams& p, int mw, hipStream_t stream) {
 // variant 0: BK 64, 2 LDS stages, 2 blocks/CU.  variant 2 / 3: BK 32, 2 / 3 LDS stages, 4 / 3 blocks/CU.
 // variant 4: 3x3 halo-patch kernel (geometry from ph_conv_halo_plan).
 int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t stream) {
+  if (p.stem) return launch_halo_stem(p, stream);
   if (variant == 4 || variant == 5) {  // 5: 8-wave blocks
     const int mw = variant == 5 ? 4 : 2;
     switch (nrep) {
