@@ -408,7 +408,8 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       o.variant = want;
       p.pool = d.pool;
       if (d.pool && want != 4 && want != 5) o.variant = 4;  // only the halo kernel pools
-      if ((o.variant == 4 || o.variant == 5) && !ph_conv_halo_plan(p, d.kh, d.f32_coff >= 0)) {
+      if ((want == 4 || want == 5 || want == 6) && d.kh == 1) o.variant = 6;  // 1x1 through the halo pipeline
+      if ((o.variant == 4 || o.variant == 5 || o.variant == 6) && !ph_conv_halo_plan(p, d.kh, d.f32_coff >= 0)) {
         if (d.pool) {
           ph_set_error("ph_net_build: op %d: fused pooling not applicable", i);
           return -1;
@@ -518,7 +519,7 @@ static int run_ops(ph_ctx* c, int B, bool timed) {
     } else {
       o.cp.B = B;
       o.cp.M = B * o.cp.H * o.cp.W;
-      if (o.variant == 4 || o.variant == 5) ph_conv_halo_plan(o.cp, 3, false);  // tile count follows B
+      if (o.variant >= 4) ph_conv_halo_plan(o.cp, o.d.kh, o.d.f32_coff >= 0);  // tile count follows B
       if (ph_launch_conv(o.cp, o.nrep, o.variant, c->stream)) return -1;
     }
   }
@@ -564,6 +565,7 @@ int ph_op_kernel(ph_ctx* c, int op, char* name, int cap) {
   if (o.skip) snprintf(name, cap, "(fused into the next op)");
   else if (o.d.type == PH_OP_POOL) snprintf(name, cap, "maxpool2x2_kernel");
   else if (o.cp.stem) snprintf(name, cap, "conv3x3_halo_kernel<2, 4, false, true>");
+  else if (o.variant == 6) snprintf(name, cap, "conv3x3_halo_kernel<%d, 2, false, false, 1>", o.nrep);
   else if (o.variant == 4 || o.variant == 5)
     snprintf(name, cap, "conv3x3_halo_kernel<%d, %d, %s>", o.nrep, o.variant == 5 ? 4 : 2, o.cp.debug ? "true" : "false");
   else if (o.variant == 2 || o.variant == 3) snprintf(name, cap, "conv_igemm_s_kernel<%d, %d>", o.nrep, o.variant);

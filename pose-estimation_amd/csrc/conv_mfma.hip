@@ -536,7 +536,24 @@ static int launch_s(const PhConvParams& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------
 #define HALO_BM 256
 
-template <int NREP, int MW, bool DBG, bool STEM = false>  // MW waves along M x 2 along N
+#define PH_WAIT_VMCNT(n)                                            \
+  do {                                                              \
+    switch (n) {                                                    \
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; \
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break; \
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break; \
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break; \
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break; \
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break; \
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break; \
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       \
+    }                                                               \
+  } while (0)
+
+// TAPS = 9: 3x3 conv (halo patch, 9 K steps per 32-channel chunk).  TAPS = 1: 1x1 conv through the same
+// pipeline: the "patch" of a chunk is just the tile's 256 pixels, lives for one K step, and rotates through
+// three buffers (halo_mode 2: tiles are 256-long runs of the unpadded pixel index).
+template <int NREP, int MW, bool DBG, bool STEM = false, int TAPS = 9>  // MW waves along M x 2 along N
 __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConvParams p) {
   constexpr int BN = 32 * NREP;
   constexpr int NW = 2 * MW;                   // waves per block
@@ -549,9 +566,10 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   constexpr int B_STAGE = NBI * 1024;
   constexpr int NBS = 3;
   constexpr int CROWB = BN * 2 + 16;
+  constexpr int NPB = TAPS == 9 ? 2 : 3;       // patch buffers
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int patch_bytes = p.NI * 1024;
-  char* const bring = lds + 2 * patch_bytes;
+  char* const bring = lds + NPB * patch_bytes;
   float* const s_bias = (float*)(bring + NBS * B_STAGE);
   float* const s_slope = s_bias + 128;
   char* const s_in = (char*)(s_slope + 128);   // STEM: 20x20 pixel x 16 B input patch of the producer conv
@@ -576,7 +594,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   // tile geometry: centre index of output row 0 / of the patch origin
   int Qc0;               // centre index of output row 0
   int tb = 0, ty0 = 0, tx0 = 0;  // mode 1: image and origin of the 16x16 tile
-  if (p.halo_mode == 0) {
+  if (TAPS == 1) {
+    Qc0 = mt * HALO_BM;  // halo_mode 2: first unpadded pixel index m of the tile
+  } else if (p.halo_mode == 0) {
     Qc0 = p.q_first + mt * HALO_BM;
   } else {
     const int tx = mt % p.tiles_x;
@@ -606,9 +626,20 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     int idx = u * NW + wave;
     idx = idx < p.NI ? idx : p.NI - 1;
     const int j = idx * 16 + (lane >> 2);
-    int jr = (int)ph_div((unsigned)j, p.magic_pr, (unsigned)p.PR);
-    jr = jr < p.PCLIP ? jr : p.PCLIP;
-    int Q = Qbase + j + jr * (Wp - p.PR);
+    int Q;
+    if (TAPS == 1) {
+      int m = Qc0 + j;
+      m = m < p.M ? m : p.M - 1;
+      const int hw = p.H * p.W;
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      const int y = rem / p.W;
+      Q = (b * Hp + y + pi) * Wp + (rem - y * p.W) + pi;
+    } else {
+      int jr = (int)ph_div((unsigned)j, p.magic_pr, (unsigned)p.PR);
+      jr = jr < p.PCLIP ? jr : p.PCLIP;
+      Q = Qbase + j + jr * (Wp - p.PR);
+    }
     Q = Q < 0 ? 0 : (Q < p.NQ ? Q : p.NQ - 1);
     a_src[u] = ((unsigned)Q * (unsigned)p.in_Cs + (unsigned)(p.in_coff + lchunk * 8)) * 2u;  // BYTE offset
   }
@@ -624,7 +655,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   for (int i = 0; i < NBW; i++) nb_w += wave + i * NW < NBI ? 1 : 0;
 
   const int nchunks = p.cin_read >> 5;
-  const int ns = nchunks * 9;
+  const int ns = nchunks * TAPS;
 
   auto load_b = [&](int t, int cc, int slot) {  // weight slice of (tap t, chunk cc)
     const unsigned k0 = (unsigned)(t * p.cin_read + cc * 32) * 2u;
@@ -645,7 +676,8 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 
   // ---- fragment read addresses ---------------------------------------------
   const int fr = lane & 15, fq = lane >> 4;
-  const int pjl = wm * IB * p.SI + fr;          // + kh*SKH + kw + i*SI
+  const int SI = TAPS == 1 ? 16 : p.SI;
+  const int pjl = wm * IB * SI + fr;            // + kh*SKH + kw + i*SI
   const int b_rd = (wn * (BN / 2) + fr) * 64 + ((fq * 16) ^ ((fr & 4) << 3));
 
   f32x4 acc[IB][NREP];
@@ -662,8 +694,12 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   load_b(0, 0, 0);
   int prev_cnt = 0;  // LDS-DMA instructions this wave issued in the previous step
   if (ns > 1) {
-    load_b(1, 0, 1);
+    load_b(TAPS == 1 ? 0 : 1, TAPS == 1 ? 1 : 0, 1);
     prev_cnt = nb_w;
+    if constexpr (TAPS == 1) {
+#pragma unroll
+      for (int u = 0; u < NPC; u++) prev_cnt += load_a(u, 1, 1);
+    }
   }
   if constexpr (STEM) {
     // ---- stem: this conv's 18x18 x 64-channel input patch = ReLU(conv3x3(8-channel frame patch)) ----
@@ -741,18 +777,16 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     for (int e = 0; e < 8; e++) bfr[j][e] = (bf16)0.f;
 
   int bslot = 0;
+  int pbuf = 0;  // patch buffer of chunk cc
   for (int cc = 0; cc < nchunks; cc++) {
-    const char* patch = lds + (cc & 1) * patch_bytes;
+    const char* patch = lds + pbuf * patch_bytes;
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-      const int s = cc * 9 + t;
+    for (int t = 0; t < TAPS; t++) {
+      const int s = cc * TAPS + t;
       long long ta = 0;
       if (dbg_t) ta = clock64();
       // everything issued before the previous step has landed
-      if (prev_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if (prev_cnt == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (prev_cnt == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PH_WAIT_VMCNT(prev_cnt);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (dbg_t) tw += clock64() - ta;
@@ -760,19 +794,29 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       prev_cnt = 0;
       if (s + 2 < ns && !(DBG && (p.debug & 2))) {
         int t2n = t + 2, c2n = cc;
-        if (t2n >= 9) { t2n -= 9; c2n++; }
+        while (t2n >= TAPS) { t2n -= TAPS; c2n++; }
         int sl = bslot + 2;
         sl = sl >= NBS ? sl - NBS : sl;
         load_b(t2n, c2n, sl);
         prev_cnt = nb_w;
       }
-      if (!STEM && t < NPC && cc + 1 < nchunks && !(DBG && (p.debug & 1))) prev_cnt += load_a(t, cc + 1, (cc + 1) & 1);
+      if constexpr (TAPS == 1) {  // the whole patch of chunk cc+2
+        if (cc + 2 < nchunks) {
+          int nb2 = pbuf + 2;
+          nb2 = nb2 >= NPB ? nb2 - NPB : nb2;
+#pragma unroll
+          for (int u = 0; u < NPC; u++) prev_cnt += load_a(u, cc + 2, nb2);
+        }
+      } else {
+        if (!STEM && t < NPC && cc + 1 < nchunks && !(DBG && (p.debug & 1)))
+          prev_cnt += load_a(t, cc + 1, (cc + 1) & 1);
+      }
 
       // (the asm keeps the 72 (tap, i) read addresses from being hoisted out of the chunk loop
       // into registers the accumulators need)
       int pv = pjl;
       asm volatile("" : "+v"(pv));
-      const int pj0 = pv + (t / 3) * p.SKH + (t % 3);
+      const int pj0 = TAPS == 1 ? pv : pv + (t / 3) * p.SKH + (t % 3);
       const char* bb = bring + bslot * B_STAGE + b_rd;
       if constexpr (PIPE) {
         // Software pipeline across the barrier: the fragments of step s are read here, right
@@ -792,7 +836,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
           } else {
             asm volatile("" ::"v"(af[i]));
           }
-          const int pj = pj0 + i * p.SI;
+          const int pj = pj0 + i * SI;
           af[i] = *(const bf16x8*)(patch + pj * 64 + ((fq * 16) ^ ((pj & 4) << 3)));
         }
         // pin the interleave (NREP MFMAs, one A-fragment read, ...): left alone the scheduler
@@ -812,7 +856,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         for (int j = 0; j < NREP; j++) bfr[j] = *(const bf16x8*)(bb + j * 1024);
 #pragma unroll
         for (int i = 0; i < IB; i++) {
-          const int pj = pj0 + i * p.SI;
+          const int pj = pj0 + i * SI;
           af[i] = *(const bf16x8*)(patch + pj * 64 + ((fq * 16) ^ ((pj & 4) << 3)));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -829,6 +873,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       }
       bslot = bslot + 1 == NBS ? 0 : bslot + 1;
     }
+    pbuf = pbuf + 1 == NPB ? 0 : pbuf + 1;
   }
   if constexpr (PIPE) {  // MFMAs of the last step
 #pragma unroll
@@ -860,6 +905,14 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   // per output row: {batch index or -1, y << 16 | x} (interior coordinates)
   int2* s_row = (int2*)bring;
   if (tid >= HALO_BM) {
+  } else if (TAPS == 1) {  // output row tid is unpadded pixel index Qc0 + tid
+    const int m = Qc0 + tid;
+    const int hw = p.H * p.W;
+    const int mc = m < p.M ? m : p.M - 1;
+    const int b = mc / hw;
+    const int rem = mc - b * hw;
+    const int y = rem / p.W;
+    s_row[tid] = make_int2(m < p.M ? b : -1, (y << 16) | (rem - y * p.W));
   } else if (p.halo_mode == 0) {  // output row tid is padded-linear pixel Qc0 + tid: border pixels are dropped
     const int Qc = Qc0 + tid;
     const int HWp = Hp * Wp;
@@ -876,6 +929,22 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   }
   constexpr int VPR = BN / 8;
   const int nvalid = p.cout - n0;
+  if (p.f32_out) {  // network output: fp32 NCHW straight from the accumulators (16 consecutive pixels per store)
+    __syncthreads();
+    const int hw = p.H * p.W;
+#pragma unroll
+    for (int i = 0; i < IB; i++) {
+      const int2 ri = s_row[wm * IB * 16 + i * 16 + fr];
+      if (ri.x < 0) continue;
+      float* o = p.f32_out + ((size_t)ri.x * p.f32_C + p.f32_coff + n0 + cbase) * hw + (ri.y >> 16) * p.W + (ri.y & 0xffff);
+#pragma unroll
+      for (int j = 0; j < NREP; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (cbase + j * 16 + e < nvalid) o[(size_t)(j * 16 + e) * hw] = acc[i][j][e];
+    }
+  }
+  if (p.n_dst > 0)
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     if (half) __syncthreads();  // store reads of the first half are done
@@ -953,6 +1022,21 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 
 // Geometry of the halo kernel for one conv; returns false if the op does not fit it.
 bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
+  if (kh == 1 && p.KW == 1) {  // 1x1: halo_mode 2, TAPS = 1 instantiation
+    if ((p.cin_read & 31) || p.pool || p.stem || (!has_f32 && p.n_dst < 1)) return false;
+    if ((unsigned long long)p.NQ * p.in_Cs * 2ull >= 0xffffffffull ||
+        (unsigned long long)p.cout_pad * p.Kpad * 2ull >= 0xffffffffull)
+      return false;
+    p.halo_mode = 2;
+    p.NI = 16;
+    p.SKH = 0;
+    p.SI = 16;
+    p.PR = 1;
+    p.PCLIP = 0;
+    p.magic_pr = ph_magic(1);
+    p.n_mtiles = (p.M + HALO_BM - 1) / HALO_BM;
+    return true;
+  }
   if (kh != 3 || p.KW != 3 || (p.cin_read & 31) || has_f32 || p.in_pad < 1 || p.n_dst < 1) return false;
   // the kernel addresses input and weights with 32-bit byte offsets
   if ((unsigned long long)p.NQ * p.in_Cs * 2ull >= 0xffffffffull ||
@@ -1006,6 +1090,24 @@ static int launch_halo(const PhConvParams& p, hipStream_t stream) {
   return 0;
 }
 
+template <int NREP>
+static int launch_halo_1x1(const PhConvParams& p, hipStream_t stream) {
+  constexpr int BN = 32 * NREP;
+  const int ldsz = 3 * 16 * 1024 + 3 * (BN / 16) * 1024 + 1024;
+  static bool attr = false;
+  if (!attr) {
+    PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<NREP, 2, false, false, 1>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, ldsz));
+    attr = true;
+  }
+  PhConvParams q = p;
+  q.n_ntiles = (p.cout + BN - 1) / BN;
+  hipLaunchKernelGGL((conv3x3_halo_kernel<NREP, 2, false, false, 1>), dim3(q.n_mtiles * q.n_ntiles), dim3(256), ldsz,
+                     stream, q);
+  PH_CHECK(hipGetLastError());
+  return 0;
+}
+
 static int launch_halo_stem(const PhConvParams& p, hipStream_t stream) {
   const int ldsz = 2 * p.NI * 1024 + 3 * 4 * 1024 + 1024 + 7 * 1024;
   static bool attr = false;
@@ -1031,6 +1133,15 @@ static int launch_halo_sel(const PhConvParams& p, int mw, hipStream_t stream) {
 // variant 4: 3x3 halo-patch kernel (geometry from ph_conv_halo_plan).
 int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t stream) {
   if (p.stem) return launch_halo_stem(p, stream);
+  if (variant == 6) {  // 1x1 through the halo pipeline
+    switch (nrep) {
+      case 1: return launch_halo_1x1<1>(p, stream);
+      case 2: return launch_halo_1x1<2>(p, stream);
+      case 3: return launch_halo_1x1<3>(p, stream);
+      case 4: return launch_halo_1x1<4>(p, stream);
+      default: ph_set_error("ph_launch_conv: bad nrep %d", nrep); return -1;
+    }
+  }
   if (variant == 4 || variant == 5) {  // 5: 8-wave blocks
     const int mw = variant == 5 ? 4 : 2;
     switch (nrep) {
