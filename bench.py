@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--per-op", action="store_true", help="print a per-op time table to stderr")
+    ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (engines / HIP streams)")
     ap.add_argument("--h2d", action="store_true",
                     help="frames start in pinned HOST memory and are copied in every step (PCIe-inclusive "
                          "rate for DESIGN.md; never the headline value)")
@@ -84,62 +85,71 @@ def main():
     net = caffe_io.parse_prototxt(caffe_io.body25_prototxt(NET_H, NET_W))
     weights = graph.random_weights(net, seed=0)
     plan = graph.build_plan(net, weights)
-    stream = torch.cuda.current_stream().cuda_stream
-    eng = Engine(local_rank, stream)
-    eng.build(plan, B)
+    # `--streams S` (default 2) batches in flight per GPU: S engines (own HIP stream, own activation buffers,
+    # shared nothing), step i runs on engine i % S.  Consecutive batches are independent, so the latency-bound
+    # decode kernels and the partial last waves of one batch's convs overlap the next batch's convs.
+    S = max(1, args.streams)
+    tstreams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    engs = []
+    for ts in tstreams:
+        e = Engine(local_rank, ts.cuda_stream)
+        e.build(plan, B)
+        engs.append(e)
+    eng = engs[0]
     flops_frame = plan.flops_per_frame()
     conv_mask = np.array([o["type"] == _ffi.PH_OP_CONV for o in plan.ops])
 
     from posehip import synth
     frames_host = torch.from_numpy(synth.synth_frames(1000 + rank, B, NET_H, NET_W)).pin_memory()
-    frames = frames_host.to(dev)
     J = BODY_25.n_parts
-    host_n = torch.empty((B,), dtype=torch.int32).pin_memory()
-    host_kp = torch.empty((B, MAX_PEOPLE, J, 3), dtype=torch.float32).pin_memory()
-    host_sc = torch.empty((B, MAX_PEOPLE), dtype=torch.float32).pin_memory()
-
-    conv_ms_total = 0.0
-    op_ms_total = np.zeros(len(plan.ops))
-    decode_ms = np.zeros(3)
-
-    def step(timed):
-        nonlocal conv_ms_total, decode_ms, op_ms_total
-        if args.h2d:
-            frames.copy_(frames_host, non_blocking=True)
-        eng.preprocess(frames, _ffi.PH_PRE_NATIVE)
-        eng.forward_timed(B, wait=False)
-        eng.decode_v2_dev(BODY_25, B, NET_H, NET_W, 1.0, MAX_PEOPLE)
-        # results to pinned host memory (rank-local) ...
-        eng.decode_v2_results(host_n, host_kp, host_sc)
-        if world > 1:  # ... and one RCCL all_gather of the padded tensors (rank 0 keeps it)
-            eng.decode_v2_results(g["n"], g["kp"], g["sc"])
-            dist.all_gather_into_tensor(g["N"], g["n"])
-            dist.all_gather_into_tensor(g["KP"], g["kp"])
-            dist.all_gather_into_tensor(g["SC"], g["sc"])
-        torch.cuda.current_stream().synchronize()
-        if timed:
-            ms = eng.forward_times()
-            conv_ms_total += float(ms[conv_mask].sum())
-            op_ms_total += ms
-            decode_ms += np.array(eng.decode_v2_times())
-
+    bufs = []
+    for k in range(S):
+        d = {"frames": frames_host.to(dev),
+             "n": torch.empty((B,), dtype=torch.int32).pin_memory(),
+             "kp": torch.empty((B, MAX_PEOPLE, J, 3), dtype=torch.float32).pin_memory(),
+             "sc": torch.empty((B, MAX_PEOPLE), dtype=torch.float32).pin_memory()}
+        if world > 1:  # 39 KB/frame: latency-bound, far below one xGMI link
+            d["gn"] = torch.empty((B,), dtype=torch.int32, device=dev)
+            d["gkp"] = torch.empty((B, MAX_PEOPLE, J, 3), dtype=torch.float32, device=dev)
+            d["gsc"] = torch.empty((B, MAX_PEOPLE), dtype=torch.float32, device=dev)
+        bufs.append(d)
     g = {}
-    if world > 1:  # 39 KB/frame: latency-bound, far below one xGMI link
-        g["n"] = torch.empty((B,), dtype=torch.int32, device=dev)
-        g["kp"] = torch.empty((B, MAX_PEOPLE, J, 3), dtype=torch.float32, device=dev)
-        g["sc"] = torch.empty((B, MAX_PEOPLE), dtype=torch.float32, device=dev)
+    if world > 1:
         g["N"] = torch.empty((world * B,), dtype=torch.int32, device=dev)
         g["KP"] = torch.empty((world * B, MAX_PEOPLE, J, 3), dtype=torch.float32, device=dev)
         g["SC"] = torch.empty((world * B, MAX_PEOPLE), dtype=torch.float32, device=dev)
+    cur = torch.cuda.current_stream()
 
-    for _ in range(args.warmup):
-        step(False)
+    def step(i):
+        """One pass of the hot path over one batch of B frames (enqueued; completes asynchronously)."""
+        k = i % S
+        e, ts, d = engs[k], tstreams[k], bufs[k]
+        ts.synchronize()           # the batch this engine ran S steps ago has delivered its keypoints
+        if world > 1:
+            ts.wait_stream(cur)    # ... and its all_gather has read the device result buffers
+        if args.h2d:
+            with torch.cuda.stream(ts):
+                d["frames"].copy_(frames_host, non_blocking=True)
+        e.preprocess(d["frames"], _ffi.PH_PRE_NATIVE)
+        e.forward(B)
+        e.decode_v2_dev(BODY_25, B, NET_H, NET_W, 1.0, MAX_PEOPLE)
+        # results to pinned host memory (rank-local) ...
+        e.decode_v2_results(d["n"], d["kp"], d["sc"])
+        if world > 1:  # ... and one RCCL all_gather of the padded tensors (rank 0 keeps it)
+            e.decode_v2_results(d["gn"], d["gkp"], d["gsc"])
+            cur.wait_stream(ts)
+            dist.all_gather_into_tensor(g["N"], d["gn"])
+            dist.all_gather_into_tensor(g["KP"], d["gkp"])
+            dist.all_gather_into_tensor(g["SC"], d["gsc"])
+
+    for i in range(args.warmup):
+        step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -148,6 +158,24 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # Kernel durations for the roofline: the same steps once more on ONE engine, serialized, with a HIP event
+    # around every op on its stream (under --streams > 1 the timed region overlaps kernels of different
+    # batches, so per-kernel durations there would include the other batch's share of the chip).
+    conv_ms_total = 0.0
+    op_ms_total = np.zeros(len(plan.ops))
+    decode_ms = np.zeros(3)
+    n_prof = max(1, min(args.steps, 10)) if rank == 0 else 0
+    for _ in range(n_prof):
+        eng.preprocess(bufs[0]["frames"], _ffi.PH_PRE_NATIVE)
+        eng.forward_timed(B, wait=False)
+        eng.decode_v2_dev(BODY_25, B, NET_H, NET_W, 1.0, MAX_PEOPLE)
+        tstreams[0].synchronize()
+        ms = eng.forward_times()
+        conv_ms_total += float(ms[conv_mask].sum())
+        op_ms_total += ms
+        decode_ms += np.array(eng.decode_v2_times())
+    frames = bufs[0]["frames"]
 
     if rank == 0 and args.per_op:
         ms = eng.forward_timed(B)
@@ -168,7 +196,7 @@ def main():
             print("real-engine parity: not available on this host (cv2 / Caffe model files absent)", file=sys.stderr)
         fps = world * B * args.steps / dt
         conv_s = conv_ms_total / 1e3
-        achieved = flops_frame * B * args.steps / conv_s / 1e12 if conv_s > 0 else 0.0
+        achieved = flops_frame * B * n_prof / conv_s / 1e12 if conv_s > 0 else 0.0
         n_conv = int(conv_mask.sum())
         # dominant kernel = the instantiation with the largest share of the timed region; its
         # achieved rate = algorithmic FLOPs of its launches / their HIP-event durations
@@ -179,8 +207,8 @@ def main():
             if c:
                 a = by_k.setdefault(kname, [0.0, 0.0, 0])
                 a[0] += t
-                a[1] += f * args.steps
-                a[2] += args.steps
+                a[1] += f * n_prof
+                a[2] += n_prof
         dom = max(by_k, key=lambda k: by_k[k][0])
         d_ms, d_fl, d_n = by_k[dom]
         d_ach = d_fl / (d_ms / 1e3) / 1e12 if d_ms > 0 else 0.0
@@ -200,21 +228,23 @@ def main():
                                    "(BASELINE configs[1])",
                        "batch_per_gpu": B, "net_resolution": f"{NET_W}x{NET_H}", "weights": "random He-normal",
                        "frames": "pinned host, H2D every step" if args.h2d else "resident in HBM",
+                       "batches_in_flight_per_gpu": S,
                        "parallelism": f"frame-parallel x{world}, RCCL keypoint all_gather"},
             "roofline": {"bound": "mfma", "achieved": round(d_ach, 2), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(d_ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": dom,
-                         "launches_per_step": d_n // args.steps,
+                         "launches_per_step": d_n // n_prof,
                          "avg_launch_ms": round(d_ms / max(1, d_n), 4),
                          "algorithmic_gflop_per_launch": round(d_fl / max(1, d_n) / 1e9, 2),
-                         "kernel_ms_per_step": round(d_ms / args.steps, 3),
+                         "kernel_ms_per_step": round(d_ms / n_prof, 3),
+                         "measured": f"HIP events per op, {n_prof} serialized steps on one engine after the timed region",
                          "all_conv": {"achieved": round(achieved, 2), "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                                       "launches_per_step": n_conv,
-                                      "conv_ms_per_step": round(conv_ms_total / args.steps, 3),
+                                      "conv_ms_per_step": round(conv_ms_total / n_prof, 3),
                                       "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
-                                      "per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3)
+                                      "per_kernel_ms_per_step": {k: round(v[0] / n_prof, 3)
                                                                  for k, v in sorted(by_k.items())}},
-                         "decode_ms_per_step": [round(float(x) / args.steps, 3) for x in decode_ms]},
+                         "decode_ms_per_step": [round(float(x) / n_prof, 3) for x in decode_ms]},
         }
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(net, weights, BODY_25, args.cpu_frames, 1000)
