@@ -564,10 +564,11 @@ int ph_op_kernel(ph_ctx* c, int op, char* name, int cap) {
   const Op& o = c->ops[op];
   if (o.skip) snprintf(name, cap, "(fused into the next op)");
   else if (o.d.type == PH_OP_POOL) snprintf(name, cap, "maxpool2x2_kernel");
-  else if (o.cp.stem) snprintf(name, cap, "conv3x3_halo_kernel<2, 4, false, true>");
+  else if (o.cp.stem) snprintf(name, cap, "conv3x3_halo_kernel<2, 4, false, true, 9>");
   else if (o.variant == 6) snprintf(name, cap, "conv3x3_halo_kernel<%d, 2, false, false, 1>", o.nrep);
   else if (o.variant == 4 || o.variant == 5)
-    snprintf(name, cap, "conv3x3_halo_kernel<%d, %d, %s>", o.nrep, o.variant == 5 ? 4 : 2, o.cp.debug ? "true" : "false");
+    snprintf(name, cap, "conv3x3_halo_kernel<%d, %d, %s, false, 9>", o.nrep, o.variant == 5 ? 4 : 2,
+             o.cp.debug ? "true" : "false");
   else if (o.variant == 2 || o.variant == 3) snprintf(name, cap, "conv_igemm_s_kernel<%d, %d>", o.nrep, o.variant);
   else snprintf(name, cap, "conv_igemm_kernel<%d>", o.nrep);
   return 0;
