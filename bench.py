@@ -74,10 +74,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # POSEHIP_BENCH_BACKEND=gloo + several ranks on one card rehearses the N > 1 control flow on a 1-GPU box
+    backend = os.environ.get("POSEHIP_BENCH_BACKEND", "nccl")
+    local_rank %= torch.cuda.device_count()
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B = args.batch
@@ -115,10 +121,14 @@ def main():
         bufs.append(d)
     g = {}
     if world > 1:
-        g["N"] = torch.empty((world * B,), dtype=torch.int32, device=dev)
-        g["KP"] = torch.empty((world * B, MAX_PEOPLE, J, 3), dtype=torch.float32, device=dev)
-        g["SC"] = torch.empty((world * B, MAX_PEOPLE), dtype=torch.float32, device=dev)
+        gdev = dev if backend == "nccl" else torch.device("cpu")
+        g["N"] = torch.empty((world * B,), dtype=torch.int32, device=gdev)
+        g["KP"] = torch.empty((world * B, MAX_PEOPLE, J, 3), dtype=torch.float32, device=gdev)
+        g["SC"] = torch.empty((world * B, MAX_PEOPLE), dtype=torch.float32, device=gdev)
     cur = torch.cuda.current_stream()
+    trace = (lambda *a: print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)) if os.environ.get("BENCH_TRACE") \
+        else (lambda *a: None)
+    trace("engines built")
 
     def step(i):
         """One pass of the hot path over one batch of B frames (enqueued; completes asynchronously)."""
@@ -135,15 +145,22 @@ def main():
         e.decode_v2_dev(BODY_25, B, NET_H, NET_W, 1.0, MAX_PEOPLE)
         # results to pinned host memory (rank-local) ...
         e.decode_v2_results(d["n"], d["kp"], d["sc"])
-        if world > 1:  # ... and one RCCL all_gather of the padded tensors (rank 0 keeps it)
+        if world > 1 and backend == "nccl":  # ... and one RCCL all_gather of the padded tensors (rank 0 keeps it)
             e.decode_v2_results(d["gn"], d["gkp"], d["gsc"])
             cur.wait_stream(ts)
             dist.all_gather_into_tensor(g["N"], d["gn"])
             dist.all_gather_into_tensor(g["KP"], d["gkp"])
             dist.all_gather_into_tensor(g["SC"], d["gsc"])
+        elif world > 1:  # rehearsal backend (gloo): same control flow, gather of the host copies
+            ts.synchronize()
+            dist.all_gather_into_tensor(g["N"], d["n"])
+            dist.all_gather_into_tensor(g["KP"], d["kp"])
+            dist.all_gather_into_tensor(g["SC"], d["sc"])
+        trace("step", i, "enqueued")
 
     for i in range(args.warmup):
         step(i)
+    trace("warmup done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -154,8 +171,9 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    trace("timed region done", dt)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
