@@ -1,0 +1,84 @@
+"""Several batches in flight on one GPU.
+
+Frames of different batches never interact, so batch k+1's convolutions can run while batch k is
+still in its latency-bound decode kernels and in the partial last wave of its conv launches.  `BatchPipeline`
+keeps `depth` engines (one ``ph_ctx`` = one HIP stream + its own activation buffers each) over one plan and
+deals submitted batches to them round-robin; results come back in submission order.  This is the batched
+counterpart of calling ``PyOpenPoseNative.predict`` in a loop (openpose/native/python/skeleton.py:444-450) and
+what ``bench.py`` times (there hand-rolled, because it also orders an RCCL gather behind each batch).
+"""
+import numpy as np
+
+from . import _ffi
+from .engine import Engine
+
+
+class BatchPipeline:
+    def __init__(self, plan, batch, model, net_h, net_w, device=0, depth=2, max_people=128,
+                 pre_mode=_ffi.PH_PRE_NATIVE, scale=1.0):
+        import torch
+        if not torch.cuda.is_available():
+            raise _ffi.PosehipError("BatchPipeline needs a GPU (no CPU fallback)")
+        self._torch = torch
+        self.batch, self.model, self.net_h, self.net_w = batch, model, net_h, net_w
+        self.max_people, self.pre_mode, self.scale = max_people, pre_mode, scale
+        dev = torch.device("cuda", device)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, depth))]
+        self.engines = []
+        self.out = []
+        J = model.n_parts
+        for ts in self.streams:
+            e = Engine(device, ts.cuda_stream)
+            e.build(plan, batch)
+            self.engines.append(e)
+            self.out.append((torch.empty((batch,), dtype=torch.int32).pin_memory(),
+                             torch.empty((batch, max_people, J, 3), dtype=torch.float32).pin_memory(),
+                             torch.empty((batch, max_people), dtype=torch.float32).pin_memory()))
+        self._pending = [None] * len(self.streams)   # per engine: (ticket, B) of the batch it is running
+        self._done = {}
+        self._next = 0
+
+    def _collect(self, k):
+        if self._pending[k] is None:
+            return
+        self.streams[k].synchronize()
+        ticket, B = self._pending[k]
+        n, kp, sc = self.out[k]
+        self._done[ticket] = (n[:B].numpy().copy(), kp[:B].numpy().copy(), sc[:B].numpy().copy())
+        self._pending[k] = None
+
+    def submit(self, frames):
+        """frames: contiguous CUDA u8 tensor [B<=batch, H0, W0, 3] BGR (must stay alive until `result`).
+        Returns a ticket; the work is only enqueued."""
+        B = int(frames.shape[0])
+        if B < 1 or B > self.batch:
+            raise ValueError(f"batch {B} outside [1, {self.batch}]")
+        k = self._next % len(self.engines)
+        self._collect(k)                      # the batch this engine ran `depth` submissions ago
+        e = self.engines[k]
+        self.streams[k].wait_stream(self._torch.cuda.current_stream())   # frames were produced on the caller's stream
+        e.preprocess(frames, self.pre_mode)
+        e.forward(B)
+        e.decode_v2_dev(self.model, B, self.net_h, self.net_w, self.scale, self.max_people)
+        e.decode_v2_results(*self.out[k])
+        ticket = self._next
+        self._pending[k] = (ticket, B)
+        self._next += 1
+        return ticket
+
+    def result(self, ticket):
+        """(n_people i32[B], keypoints f32[B, max_people, J, 3], scores f32[B, max_people]) of a ticket."""
+        if ticket not in self._done:
+            for k, p in enumerate(self._pending):
+                if p is not None and p[0] == ticket:
+                    self._collect(k)
+        if ticket not in self._done:
+            raise KeyError(f"unknown or already collected ticket {ticket}")
+        return self._done.pop(ticket)
+
+    def close(self):
+        for k in range(len(self.engines)):
+            self._collect(k)
+        for e in self.engines:
+            e.close()
+        self.engines = []

@@ -181,3 +181,31 @@ def test_real_images_preprocess_matches_golden(engine):
         ref = want_u8[None].astype(np.float32) * np.float32(1 / 255.0)
         ref16 = ((ref.view(np.uint32) + 0x7fff + ((ref.view(np.uint32) >> 16) & 1)) >> 16 << 16).astype(np.uint32)
         np.testing.assert_array_equal(got.view(np.uint32), ref16)
+
+
+def test_batch_pipeline_matches_sequential(engine):
+    """Two batches in flight on two engines/streams deliver exactly what one engine delivers batch by batch."""
+    import torch
+    from posehip.pipeline import BatchPipeline
+    from posehip.tables import BODY_25
+    h, w, B = 64, 96, 3
+    net = caffe_io.parse_prototxt(caffe_io.body25_prototxt(h, w))
+    weights = graph.random_weights(net, seed=11)
+    plan = graph.build_plan(net, weights)
+    batches = [torch.from_numpy(synth.synth_frames(70 + i, B if i != 2 else 2, h, w)).cuda() for i in range(5)]
+    engine.build(plan, B)
+    want = []
+    for f in batches:
+        nb = engine.preprocess(f, _ffi.PH_PRE_NATIVE)
+        engine.forward(nb)
+        res, extras = engine.decode_v2(BODY_25, nb, h, w, 1.0, 128)
+        want.append((extras["n_people"].copy(), res))
+    pipe = BatchPipeline(plan, B, BODY_25, h, w, device=0, depth=2)
+    tickets = [pipe.submit(f) for f in batches]
+    for t, (n, res) in zip(reversed(tickets), reversed(want)):       # any collection order
+        gn, gkp, gsc = pipe.result(t)
+        np.testing.assert_array_equal(gn, n)
+        for b, (kp, sc) in enumerate(res):
+            np.testing.assert_array_equal(gkp[b, :len(kp)], kp)
+            np.testing.assert_array_equal(gsc[b, :len(sc)], sc)
+    pipe.close()
