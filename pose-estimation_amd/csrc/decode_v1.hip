@@ -106,12 +106,15 @@ __global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __
   const int ya = y0 > 0 ? y0 - 1 : 0, yb = y0 + V1_TILE_H < H ? y0 + V1_TILE_H : H - 1;
   const int sxa = lin_x(xa, W, ws).s0, sxb = lin_x(xb, W, ws).s1;
   const int sya = lin_y(ya, H, hs).s0, syb = lin_y(yb, H, hs).s1;
+  // only the source cells this tile can reach are staged (a 16x256 tile of a 1080p map touches ~4x14 of the
+  // 46x82 cells): s_src is the sub-rectangle [sya..syb] x [sxa..sxb], row stride sw
+  const int sw = sxb - sxa + 1, sh = syb - sya + 1;
   float lm = -INFINITY;
-  for (int i = tid; i < hs * ws; i += V1_RUN_THREADS) {
-    const float v = plane[i];
+  for (int i = tid; i < sw * sh; i += V1_RUN_THREADS) {
+    const int yy = i / sw, xx = i - yy * sw;
+    const float v = plane[(sya + yy) * ws + sxa + xx];
     s_src[i] = v;
-    const int yy = i / ws, xx = i - yy * ws;
-    if (yy >= sya && yy <= syb && xx >= sxa && xx <= sxb) lm = fmaxf(lm, v);
+    lm = fmaxf(lm, v);
   }
   for (int o = 32; o > 0; o >>= 1) lm = fmaxf(lm, __shfl_xor(lm, o));
   if ((tid & 63) == 0) s_max[tid >> 6] = lm;
@@ -124,12 +127,22 @@ __global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __
   // 1. bilinear-resized heat map, tile + 1-px halo, reflect-101 at the image border
   constexpr int HW_ = V1_TILE_W + 2;
   for (int c = tid; c < HW_; c += V1_RUN_THREADS)
-    if (x0 - 1 + c <= W) s_lx[c] = lin_x(reflect101(x0 - 1 + c, W), W, ws);
-  if (tid < V1_TILE_H + 2 && y0 - 1 + tid <= H) s_ly[tid] = lin_y(reflect101(y0 - 1 + tid, H), H, hs);
+    if (x0 - 1 + c <= W) {
+      LinX t = lin_x(reflect101(x0 - 1 + c, W), W, ws);
+      t.s0 -= sxa;  // indices relative to the staged sub-rectangle
+      t.s1 -= sxa;
+      s_lx[c] = t;
+    }
+  if (tid < V1_TILE_H + 2 && y0 - 1 + tid <= H) {
+    LinX t = lin_y(reflect101(y0 - 1 + tid, H), H, hs);
+    t.s0 -= sya;
+    t.s1 -= sya;
+    s_ly[tid] = t;
+  }
   __syncthreads();
   for (int i = tid; i < (V1_TILE_H + 2) * HW_; i += V1_RUN_THREADS) {
     const int r = i / HW_, c = i - r * HW_;
-    s_heat[i] = (y0 - 1 + r <= H && x0 - 1 + c <= W) ? resize_tab(s_src, ws, s_lx[c], s_ly[r]) : 0.f;
+    s_heat[i] = (y0 - 1 + r <= H && x0 - 1 + c <= W) ? resize_tab(s_src, sw, s_lx[c], s_ly[r]) : 0.f;
   }
   __syncthreads();
   // 2. row pass  c*1/2 + (l + r)*1/4
@@ -147,12 +160,22 @@ __global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __
     s_sm[i] = inside ? t[0] * 0.5f + (t[-V1_TILE_W] + t[V1_TILE_W]) * 0.25f : -INFINITY;
   }
   __syncthreads();
-  // 4. runs: the thread on a run's first pixel walks it
+  // 4. runs: the thread on a run's first pixel walks it.  Slots are reserved per BLOCK (LDS counter, then one
+  //    global atomicAdd): a per-run global atomic on the map's single counter serialises whole blobs.
+  __shared__ int s_cnt, s_base;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
   int* cnt = n_runs + (size_t)b * n_parts + part;
   V1Run* out = runs + ((size_t)b * n_parts + part) * run_cap;
-  for (int i = tid; i < V1_TILE_H * V1_TILE_W; i += V1_RUN_THREADS) {
+  constexpr int PER_T = V1_TILE_H * V1_TILE_W / V1_RUN_THREADS;
+  V1Run mine[PER_T];
+  int myslot[PER_T];
+#pragma unroll
+  for (int k = 0; k < PER_T; k++) {
+    const int i = tid + k * V1_RUN_THREADS;
     const int r = i / V1_TILE_W, c = i - r * V1_TILE_W;
     const float* row = s_sm + r * V1_TILE_W;
+    myslot[k] = -1;
     if (row[c] > thr && (c == 0 || !(row[c - 1] > thr))) {
       float best = row[c];
       int bx = c, e = c;
@@ -163,20 +186,24 @@ __global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __
           bx = e;
         }
       }
-      const int slot = atomicAdd(cnt, 1);
-      if (slot < run_cap) {
-        V1Run rn;
-        rn.y = y0 + r;
-        rn.xs = x0 + c;
-        rn.xe = x0 + e;
-        rn.bx = x0 + bx;
-        rn.best = best;
-        out[slot] = rn;
-      } else {
-        *overflow = 1;
-      }
+      mine[k].y = y0 + r;
+      mine[k].xs = x0 + c;
+      mine[k].xe = x0 + e;
+      mine[k].bx = x0 + bx;
+      mine[k].best = best;
+      myslot[k] = atomicAdd(&s_cnt, 1);
     }
   }
+  __syncthreads();
+  if (tid == 0) s_base = s_cnt ? atomicAdd(cnt, s_cnt) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER_T; k++)
+    if (myslot[k] >= 0) {
+      const int slot = s_base + myslot[k];
+      if (slot < run_cap) out[slot] = mine[k];
+      else *overflow = 1;
+    }
 }
 
 // ---------------------------------------------------------------------------
