@@ -109,3 +109,37 @@ def test_bad_plans_fail_loudly(engine):
         engine.build(plan, 1)
     with pytest.raises(_ffi.PosehipError):
         engine.forward(1)                        # nothing built after the failure
+
+
+def test_body25_full_size_matches_oracle_and_is_batch_invariant(engine):
+    """BASELINE configs[1] geometry (BODY_25, 368x656): every production kernel path at its real shapes
+    (stem fusion, fused pooling, 16x16-tile and padded-linear halo modes, 1x1 pipeline, fp32 epilogue).
+    One frame is checked against the torch fp32 oracle (north_star tolerance 1e-2 on the heat maps); frames
+    are independent units, so frame 1 of a batch of 3 must equal the same frame run alone bit for bit; the
+    V2 decode of the GPU's own network output must equal the oracle's decode of that output bit for bit."""
+    from oracle import decode_v2, net_ref
+    from posehip import synth
+    from posehip.tables import BODY_25
+    H, W = 368, 656
+    net = caffe_io.parse_prototxt(caffe_io.body25_prototxt(H, W))
+    weights = graph.random_weights(net, seed=5)
+    plan = graph.build_plan(net, weights)
+    assert abs(plan.flops_per_frame() / 1e9 - 287.26) < 0.05
+    engine.build(plan, 3)
+    frames = synth.synth_frames(321, 3, H, W)
+    engine.preprocess(frames, _ffi.PH_PRE_NATIVE)
+    engine.forward(3)
+    got3 = engine.net_out(3)
+    x = frames[1:2].astype(np.float32).transpose(0, 3, 1, 2) * np.float32(1 / 256.0) - np.float32(0.5)
+    ref = net_ref.forward(net, weights, x)
+    assert got3.shape == (3, 78, 46, 82) and np.isfinite(got3).all()
+    err = np.abs(got3[1] - ref[0]).max()
+    assert err < 1e-2, err                                   # heat-map max abs err (north_star)
+    assert err / (np.abs(ref).max() + 1e-9) < 3e-2
+    res3, _ = engine.decode_v2(BODY_25, 3, H, W, 1.0, 128)
+    kp_ref, sc_ref = decode_v2.decode(got3[1], BODY_25, H, W, 1.0)
+    np.testing.assert_array_equal(res3[1][0], kp_ref)
+    np.testing.assert_array_equal(res3[1][1], sc_ref)
+    engine.preprocess(frames[1:2], _ffi.PH_PRE_NATIVE)
+    engine.forward(1)
+    np.testing.assert_array_equal(engine.net_out(1)[0], got3[1])
