@@ -903,7 +903,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   }
   __syncthreads();  // all fragment reads done, no LDS-DMA in flight (the last step waited for vmcnt(0))
   // per output row: {batch index or -1, y << 16 | x} (interior coordinates)
-  int2* s_row = (int2*)bring;
+  int2* s_row = (int2*)(lds + HALO_BM * CROWB);  // behind the staged output tile (which may cover every other region)
   if (tid >= HALO_BM) {
   } else if (TAPS == 1) {  // output row tid is unpadded pixel index Qc0 + tid
     const int m = Qc0 + tid;
@@ -944,29 +944,25 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
           if (cbase + j * 16 + e < nvalid) o[(size_t)(j * 16 + e) * hw] = acc[i][j][e];
     }
   }
-  if (p.n_dst > 0)
+  if (p.n_dst > 0) {
+    // the whole 256 x BN tile goes through LDS at once (bias/slope and the K-loop buffers are dead by now)
 #pragma unroll
-  for (int half = 0; half < 2; half++) {
-    if (half) __syncthreads();  // store reads of the first half are done
-    if (wm / (MW / 2) == half) {
+    for (int i = 0; i < IB; i++)
 #pragma unroll
-      for (int i = 0; i < IB; i++)
+      for (int j = 0; j < NREP; j++) {
+        bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < NREP; j++) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; e++) o[e] = (bf16)acc[i][j][e];
-          *(bf16x4*)(lds + ((wm % (MW / 2)) * IB * 16 + i * 16 + fr) * CROWB + (cbase + j * 16) * 2) = o;
-        }
-    }
+        for (int e = 0; e < 4; e++) o[e] = (bf16)acc[i][j][e];
+        *(bf16x4*)(lds + (wm * IB * 16 + i * 16 + fr) * CROWB + (cbase + j * 16) * 2) = o;
+      }
     __syncthreads();
     if (p.pool) {
-      // 2x2/2 max pool: this half holds tile rows 8*half .. 8*half+7 -> 4 x 8 pooled pixels
-      for (int v = tid; v < 32 * VPR; v += NT) {
+      // 2x2/2 max pool of the 16x16 tile -> 8 x 8 pooled pixels
+      for (int v = tid; v < 64 * VPR; v += NT) {
         const int prow = v / VPR;
         const int cv = (v - prow * VPR) * 8;
         const int r0 = (prow >> 3) * 32 + (prow & 7) * 2;
-        const int2 ri = s_row[half * 128 + r0];
+        const int2 ri = s_row[r0];
         if (ri.x < 0 || cv >= nvalid) continue;
         const int y = ri.y >> 17, x = (ri.y & 0xffff) >> 1;
         const char* sp = lds + r0 * CROWB + cv * 2;
@@ -986,23 +982,23 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
           }
         }
       }
-      continue;
-    }
-    for (int v = tid; v < 128 * VPR; v += NT) {
-      const int row = v / VPR;
-      const int cv = (v - row * VPR) * 8;
-      const int2 ri = s_row[half * 128 + row];
-      if (ri.x < 0 || cv >= nvalid) continue;
-      const int y = ri.y >> 16, x = ri.y & 0xffff;
-      const char* sp = lds + row * CROWB + cv * 2;
-      const u32x4 val = *(const u32x4*)sp;
-      for (int d = 0; d < p.n_dst; d++) {
-        const PhDst& ds = p.dst[d];
-        bf16* o = ds.base + (size_t)ds.org + ((size_t)(ri.x * ds.Hp + y) * ds.Wp + x) * ds.Cs + n0 + cv;
-        if (cv + 8 <= nvalid) {
-          *(u32x4*)o = val;
-        } else {
-          for (int e = 0; e < nvalid - cv; e++) o[e] = ((const bf16*)sp)[e];
+    } else {
+      for (int v = tid; v < HALO_BM * VPR; v += NT) {
+        const int row = v / VPR;
+        const int cv = (v - row * VPR) * 8;
+        const int2 ri = s_row[row];
+        if (ri.x < 0 || cv >= nvalid) continue;
+        const int y = ri.y >> 16, x = ri.y & 0xffff;
+        const char* sp = lds + row * CROWB + cv * 2;
+        const u32x4 val = *(const u32x4*)sp;
+        for (int d = 0; d < p.n_dst; d++) {
+          const PhDst& ds = p.dst[d];
+          bf16* o = ds.base + (size_t)ds.org + ((size_t)(ri.x * ds.Hp + y) * ds.Wp + x) * ds.Cs + n0 + cv;
+          if (cv + 8 <= nvalid) {
+            *(u32x4*)o = val;
+          } else {
+            for (int e = 0; e < nvalid - cv; e++) o[e] = ((const bf16*)sp)[e];
+          }
         }
       }
     }
@@ -1072,10 +1068,16 @@ bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
   return true;
 }
 
+// K-loop buffers, or the epilogue's staged 256 x BN bf16 tile + 256-entry row table, whichever is larger
+static int halo_lds(int loop_bytes, int bn) {
+  const int epi = HALO_BM * (bn * 2 + 16) + HALO_BM * 8;
+  return loop_bytes > epi ? loop_bytes : epi;
+}
+
 template <int NREP, int MW, bool DBG>
 static int launch_halo(const PhConvParams& p, hipStream_t stream) {
   constexpr int BN = 32 * NREP;
-  const int ldsz = 2 * p.NI * 1024 + 3 * (BN / 16) * 1024 + 1024;
+  const int ldsz = halo_lds(2 * p.NI * 1024 + 3 * (BN / 16) * 1024 + 1024, BN);
   static int attr = 0;
   if (attr < ldsz) {
     PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<NREP, MW, DBG>,
@@ -1093,7 +1095,7 @@ static int launch_halo(const PhConvParams& p, hipStream_t stream) {
 template <int NREP>
 static int launch_halo_1x1(const PhConvParams& p, hipStream_t stream) {
   constexpr int BN = 32 * NREP;
-  const int ldsz = 3 * 16 * 1024 + 3 * (BN / 16) * 1024 + 1024;
+  const int ldsz = halo_lds(3 * 16 * 1024 + 3 * (BN / 16) * 1024 + 1024, BN);
   static bool attr = false;
   if (!attr) {
     PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<NREP, 2, false, false, 1>,
@@ -1109,7 +1111,7 @@ static int launch_halo_1x1(const PhConvParams& p, hipStream_t stream) {
 }
 
 static int launch_halo_stem(const PhConvParams& p, hipStream_t stream) {
-  const int ldsz = 2 * p.NI * 1024 + 3 * 4 * 1024 + 1024 + 7 * 1024;
+  const int ldsz = halo_lds(2 * p.NI * 1024 + 3 * 4 * 1024 + 1024 + 7 * 1024, 64);
   static bool attr = false;
   if (!attr) {
     PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<2, 4, false, true>,
