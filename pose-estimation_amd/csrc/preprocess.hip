@@ -96,3 +96,37 @@ int ph_launch_preprocess(const uint8_t* frames, int B, int H0, int W0, int Hn, i
   PH_CHECK(hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Measurement helper (tools/hbm_copy.py, not part of include/posehip.h): achievable HBM bandwidth of a plain
+// 16-byte-per-lane streaming copy, the yardstick for the HBM-bound kernels.
+// ---------------------------------------------------------------------------
+__global__ void ph_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+extern "C" int ph_debug_copy_bandwidth(size_t bytes, int reps, float* gb_per_s) {
+  void *a = nullptr, *b = nullptr;
+  PH_CHECK(hipMalloc(&a, bytes));
+  PH_CHECK(hipMalloc(&b, bytes));
+  PH_CHECK(hipMemset(a, 1, bytes));
+  hipEvent_t e0, e1;
+  PH_CHECK(hipEventCreate(&e0));
+  PH_CHECK(hipEventCreate(&e1));
+  const size_t n = bytes / 16;
+  hipLaunchKernelGGL(ph_copy_kernel, dim3(256 * 16), dim3(256), 0, 0, (const u32x4*)a, (u32x4*)b, n);
+  PH_CHECK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL(ph_copy_kernel, dim3(256 * 16), dim3(256), 0, 0, (const u32x4*)a, (u32x4*)b, n);
+  PH_CHECK(hipEventRecord(e1, 0));
+  PH_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PH_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *gb_per_s = (float)(2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);  // read + write
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  return 0;
+}
