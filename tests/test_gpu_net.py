@@ -143,3 +143,26 @@ def test_body25_full_size_matches_oracle_and_is_batch_invariant(engine):
     engine.preprocess(frames[1:2], _ffi.PH_PRE_NATIVE)
     engine.forward(1)
     np.testing.assert_array_equal(engine.net_out(1)[0], got3[1])
+
+
+def test_fused_pool_and_kernel_names(engine):
+    """ph_op_desc.pool is validated (3x3, cin_read % 32 == 0, even H/W) and ph_op_kernel names what runs."""
+    h, w, spec = CASES["vgg_like"]
+    net = _tiny_net(h, w, spec)
+    weights = graph.random_weights(net, seed=7, out_gain=1.0)
+    plan = graph.build_plan(net, weights)
+    assert [o.get("pool", 0) for o in plan.ops] == [0, 1, 0, 0]          # p1 folded into c2
+    engine.build(plan, 1)
+    names = engine.op_kernels()
+    assert names[0] == "(fused into the next op)" and "true, 9>" in names[1]   # c1 computed inside c2 (stem)
+    assert names[3].endswith("1>") or names[3].startswith("conv_igemm_kernel")
+    unfused = graph.build_plan(net, weights, fuse_pool=False)
+    assert [o["type"] for o in unfused.ops].count(_ffi.PH_OP_POOL) == 1
+    odd = _tiny_net(13, 19, [("conv", "c1", "image", 64, 3, "ReLU"), ("conv", "c2", "c1", 64, 3, "ReLU"),
+                             ("pool", "p", "c2"), ("conv", "out", "p", 38, 3, None)])
+    wodd = graph.random_weights(odd, seed=1)
+    podd = graph.build_plan(odd, wodd)
+    assert all(o.get("pool", 0) == 0 for o in podd.ops)                    # odd sizes: pooling stays a separate op
+    podd.ops[1]["pool"] = 1                                                # forcing it must fail loudly
+    with pytest.raises(_ffi.PosehipError):
+        engine.build(podd, 1)
