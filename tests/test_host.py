@@ -199,3 +199,24 @@ def test_opencv_class_surface():
     with pytest.raises(FileNotFoundError):
         o.load("/nonexistent.prototxt", "/nonexistent.caffemodel", False)
     assert o.draw_skeleton(image=None) is None
+
+
+def test_compat_import_paths_resolve_to_posehip():
+    """the reference's import lines work against compat/ and land on the posehip classes."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "compat"))
+    try:
+        for m in [k for k in sys.modules if k == "openpose" or k.startswith("openpose.")]:
+            del sys.modules[m]
+        cv = importlib.import_module("openpose.opencv")
+        nat = importlib.import_module("openpose.native.python.skeleton")
+        from posehip import api_native, api_opencv
+        assert cv.PyOpenPoseOpenCV is api_opencv.PyOpenPoseOpenCV
+        assert cv.get_body_parts_and_pose_pairs("COCO")[0]["Nose"] == 0
+        assert nat.PyOpenPoseNative is api_native.PyOpenPoseNative and nat.TORSO_IDS == [1, 2, 5, 8, 9, 12]
+        assert nat.OpenPosePoseExtractor is api_native.OpenPosePoseExtractor
+    finally:
+        sys.path.remove(os.path.join(root, "compat"))
