@@ -570,7 +570,8 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int patch_bytes = p.NI * 1024;
   char* const bring = lds + NPB * patch_bytes;
-  float* const s_bias = (float*)(bring + NBS * B_STAGE);
+  // (STEM keeps 2 slots x 3 taps of weight slices instead of 3 slots x 1 tap)
+  float* const s_bias = (float*)(bring + (STEM ? 6 : NBS) * B_STAGE);
   float* const s_slope = s_bias + 128;
   char* const s_in = (char*)(s_slope + 128);   // STEM: 20x20 pixel x 16 B input patch of the producer conv
 
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   const int nchunks = p.cin_read >> 5;
   const int ns = nchunks * TAPS;
 
-  auto load_b = [&](int t, int cc, int slot) {  // weight slice of (tap t, chunk cc)
+  auto load_b = [&](int t, int cc, int slot) {  // weight slice of (tap t, chunk cc) -> slice slot `slot`
     const unsigned k0 = (unsigned)(t * p.cin_read + cc * 32) * 2u;
     const char* wbase = (const char*)p.wt;  // uniform base + 32-bit lane offset: saddr addressing, no 64-bit VGPR pairs
     char* sb = bring + slot * B_STAGE + wave * 1024;
@@ -691,9 +692,14 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #pragma unroll
     for (int u = 0; u < NPC; u++) load_a(u, 0, 0);
   }
-  load_b(0, 0, 0);
+  if constexpr (STEM) {
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++) load_b(kw, 0, kw);  // kernel row 0 of chunk 0 -> slices 0..2
+  } else {
+    load_b(0, 0, 0);
+  }
   int prev_cnt = 0;  // LDS-DMA instructions this wave issued in the previous step
-  if (ns > 1) {
+  if (!STEM && ns > 1) {
     load_b(TAPS == 1 ? 0 : 1, TAPS == 1 ? 1 : 0, 1);
     prev_cnt = nb_w;
     if constexpr (TAPS == 1) {
@@ -776,9 +782,43 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #pragma unroll
     for (int e = 0; e < 8; e++) bfr[j][e] = (bf16)0.f;
 
+  if constexpr (STEM) {
+    // Both patch chunks are resident and only 4 KB weight slices stream, so the K loop is barrier-bound:
+    // one barrier per KERNEL ROW (3 taps, 24 MFMAs per wave) instead of per tap; weight slices of row s+1
+    // are fetched into the other half of the 6-slice buffer while row s computes.
+#pragma unroll 1
+    for (int s = 0; s < 6; s++) {
+      const int cc = s / 3, kh = s - cc * 3;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 1 < 6) {
+        const int c1 = (s + 1) / 3, k1 = (s + 1) - c1 * 3;
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) load_b(k1 * 3 + kw, c1, ((s + 1) & 1) * 3 + kw);
+      }
+      const char* patch = lds + cc * patch_bytes;
+#pragma unroll
+      for (int kw = 0; kw < 3; kw++) {
+        const char* bb = bring + ((s & 1) * 3 + kw) * B_STAGE + b_rd;
+#pragma unroll
+        for (int j = 0; j < NREP; j++) bfr[j] = *(const bf16x8*)(bb + j * 1024);
+#pragma unroll
+        for (int i = 0; i < IB; i++) {
+          const int pj = pjl + kh * 18 + kw + i * 18;
+          af[i] = *(const bf16x8*)(patch + pj * 64 + ((fq * 16) ^ ((pj & 4) << 3)));
+        }
+#pragma unroll
+        for (int i = 0; i < IB; i++)
+#pragma unroll
+          for (int j = 0; j < NREP; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
   int bslot = 0;
   int pbuf = 0;  // patch buffer of chunk cc
-  for (int cc = 0; cc < nchunks; cc++) {
+  for (int cc = 0; !STEM && cc < nchunks; cc++) {
     const char* patch = lds + pbuf * patch_bytes;
 #pragma unroll
     for (int t = 0; t < TAPS; t++) {
@@ -875,7 +915,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     }
     pbuf = pbuf + 1 == NPB ? 0 : pbuf + 1;
   }
-  if constexpr (PIPE) {  // MFMAs of the last step
+  if constexpr (PIPE && !STEM) {  // MFMAs of the last step
 #pragma unroll
     for (int i = 0; i < IB; i++)
 #pragma unroll
@@ -1111,7 +1151,7 @@ static int launch_halo_1x1(const PhConvParams& p, hipStream_t stream) {
 }
 
 static int launch_halo_stem(const PhConvParams& p, hipStream_t stream) {
-  const int ldsz = halo_lds(2 * p.NI * 1024 + 3 * 4 * 1024 + 1024 + 7 * 1024, 64);
+  const int ldsz = halo_lds(2 * p.NI * 1024 + 6 * 4 * 1024 + 1024 + 7 * 1024, 64);
   static bool attr = false;
   if (!attr) {
     PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<2, 4, false, true>,
