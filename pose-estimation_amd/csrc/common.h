@@ -74,3 +74,15 @@ __device__ static inline unsigned ph_div(unsigned n, unsigned magic, unsigned d)
   } while (0)
 
 void ph_set_error(const char* fmt, ...);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember, per kernel and
+// device, the largest size already granted (`cache` = a zero-initialised static int[PH_MAX_DEVICES] per kernel).
+#define PH_MAX_DEVICES 64
+static inline int ph_ensure_lds(const void* fn, int bytes, int* cache) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PH_MAX_DEVICES) dev = 0;
+  if (cache[dev] >= bytes) return 0;
+  PH_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  cache[dev] = bytes;
+  return 0;
+}

@@ -502,12 +502,8 @@ static int launch_s(const PhConvParams& p, hipStream_t stream) {
   constexpr int BN = 32 * NREP;
   constexpr int STAGE = BM * 64 + ((BN + 63) / 64) * 64 * 64;
   constexpr int LDS = NSTAGE * STAGE + 2048;
-  static bool attr = false;
-  if (!attr) {
-    PH_CHECK(hipFuncSetAttribute((const void*)conv_igemm_s_kernel<NREP, NSTAGE>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr = true;
-  }
+  static int attr[PH_MAX_DEVICES];
+  if (ph_ensure_lds((const void*)conv_igemm_s_kernel<NREP, NSTAGE>, LDS, attr)) return -1;
   PhConvParams q = p;
   q.n_mtiles = (p.M + BM - 1) / BM;
   q.n_ntiles = (p.cout + BN - 1) / BN;
@@ -1118,12 +1114,8 @@ template <int NREP, int MW, bool DBG>
 static int launch_halo(const PhConvParams& p, hipStream_t stream) {
   constexpr int BN = 32 * NREP;
   const int ldsz = halo_lds(2 * p.NI * 1024 + 3 * (BN / 16) * 1024 + 1024, BN);
-  static int attr = 0;
-  if (attr < ldsz) {
-    PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<NREP, MW, DBG>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, ldsz));
-    attr = ldsz;
-  }
+  static int attr[PH_MAX_DEVICES];
+  if (ph_ensure_lds((const void*)conv3x3_halo_kernel<NREP, MW, DBG>, ldsz, attr)) return -1;
   PhConvParams q = p;
   q.n_ntiles = (p.cout + BN - 1) / BN;
   hipLaunchKernelGGL((conv3x3_halo_kernel<NREP, MW, DBG>), dim3(q.n_mtiles * q.n_ntiles), dim3(128 * MW), ldsz, stream,
@@ -1136,12 +1128,8 @@ template <int NREP>
 static int launch_halo_1x1(const PhConvParams& p, hipStream_t stream) {
   constexpr int BN = 32 * NREP;
   const int ldsz = halo_lds(3 * 16 * 1024 + 3 * (BN / 16) * 1024 + 1024, BN);
-  static bool attr = false;
-  if (!attr) {
-    PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<NREP, 2, false, false, 1>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, ldsz));
-    attr = true;
-  }
+  static int attr[PH_MAX_DEVICES];
+  if (ph_ensure_lds((const void*)conv3x3_halo_kernel<NREP, 2, false, false, 1>, ldsz, attr)) return -1;
   PhConvParams q = p;
   q.n_ntiles = (p.cout + BN - 1) / BN;
   hipLaunchKernelGGL((conv3x3_halo_kernel<NREP, 2, false, false, 1>), dim3(q.n_mtiles * q.n_ntiles), dim3(256), ldsz,
@@ -1152,12 +1140,8 @@ static int launch_halo_1x1(const PhConvParams& p, hipStream_t stream) {
 
 static int launch_halo_stem(const PhConvParams& p, hipStream_t stream) {
   const int ldsz = halo_lds(2 * p.NI * 1024 + 6 * 4 * 1024 + 1024 + 7 * 1024, 64);
-  static bool attr = false;
-  if (!attr) {
-    PH_CHECK(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<2, 4, false, true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, ldsz));
-    attr = true;
-  }
+  static int attr[PH_MAX_DEVICES];
+  if (ph_ensure_lds((const void*)conv3x3_halo_kernel<2, 4, false, true>, ldsz, attr)) return -1;
   PhConvParams q = p;
   q.n_ntiles = 1;
   hipLaunchKernelGGL((conv3x3_halo_kernel<2, 4, false, true>), dim3(q.n_mtiles), dim3(512), ldsz, stream, q);

@@ -548,15 +548,12 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
     ph_set_error("decode_v1: LDS budget exceeded (%zu/%zu/%zu/%zu B)", ldsA, ldsB, ldsC, ldsD);
     return -1;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    PH_CHECK(hipFuncSetAttribute((const void*)v1_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
-    PH_CHECK(hipFuncSetAttribute((const void*)v1_blobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
-    PH_CHECK(hipFuncSetAttribute((const void*)v1_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
-    PH_CHECK(hipFuncSetAttribute((const void*)v1_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lim));
-    attr_done = true;
-  }
+  static int attr[4][PH_MAX_DEVICES];
+  if (ph_ensure_lds((const void*)v1_runs_kernel, (int)lim, attr[0]) ||
+      ph_ensure_lds((const void*)v1_blobs_kernel, (int)lim, attr[1]) ||
+      ph_ensure_lds((const void*)v1_pairs_kernel, (int)lim, attr[2]) ||
+      ph_ensure_lds((const void*)v1_assemble_kernel, (int)lim, attr[3]))
+    return -1;
   V1Sizes sz;
   ph_v1_sizes(m, B, W, H, c, &sz);
   PH_CHECK(hipMemsetAsync(w.n_runs, 0, sz.n_runs, stream));

@@ -780,14 +780,12 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
                  lds3, hs, ws, Ht, Wt);
     return -1;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    PH_CHECK(hipFuncSetAttribute((const void*)nms_detect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
-    PH_CHECK(hipFuncSetAttribute((const void*)nms_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
-    PH_CHECK(hipFuncSetAttribute((const void*)paf_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
-    PH_CHECK(hipFuncSetAttribute((const void*)assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lim));
-    attr_done = true;
-  }
+  static int attr[4][PH_MAX_DEVICES];
+  if (ph_ensure_lds((const void*)nms_detect_kernel, (int)lim, attr[0]) ||
+      ph_ensure_lds((const void*)nms_refine_kernel, (int)lim, attr[1]) ||
+      ph_ensure_lds((const void*)paf_match_kernel, (int)lim, attr[2]) ||
+      ph_ensure_lds((const void*)assemble_kernel, (int)lim, attr[3]))
+    return -1;
   PhV2Sizes sz;
   ph_v2_workspace_sizes(m, B, max_people, &sz);
   PH_CHECK(hipMemsetAsync(w.peaks, 0, sz.peaks, stream));
