@@ -209,3 +209,45 @@ def test_batch_pipeline_matches_sequential(engine):
             np.testing.assert_array_equal(gkp[b, :len(kp)], kp)
             np.testing.assert_array_equal(gsc[b, :len(sc)], sc)
     pipe.close()
+
+
+def test_three_engines_on_three_threads(engine):
+    """The reference creates 3 estimator instances on 3 threads (datacollection/utils.py:17-32): contexts share
+    no mutable state, so concurrent use gives exactly the single-threaded results."""
+    import threading
+    from posehip.engine import Engine
+    from posehip.tables import BODY_25
+    h, w, B = 48, 80, 2
+    net = caffe_io.parse_prototxt(caffe_io.body25_prototxt(h, w))
+    weights = graph.random_weights(net, seed=3)
+    plan = graph.build_plan(net, weights)
+    frames = [synth.synth_frames(200 + i, B, h, w) for i in range(3)]
+    engine.build(plan, B)
+    want = []
+    for f in frames:
+        engine.preprocess(f, _ffi.PH_PRE_NATIVE)
+        engine.forward(B)
+        want.append((engine.net_out(B).copy(), engine.decode_v2(BODY_25, B, h, w, 1.0, 128)[0]))
+    got, errs = [None] * 3, []
+
+    def work(i):
+        try:
+            e = Engine(0)
+            e.build(plan, B)
+            for _ in range(5):
+                e.preprocess(frames[i], _ffi.PH_PRE_NATIVE)
+                e.forward(B)
+                got[i] = (e.net_out(B).copy(), e.decode_v2(BODY_25, B, h, w, 1.0, 128)[0])
+            e.close()
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for (o, r), (go, gr) in zip(want, got):
+        np.testing.assert_array_equal(o, go)
+        for (kp, sc), (gkp, gsc) in zip(r, gr):
+            np.testing.assert_array_equal(kp, gkp)
+            np.testing.assert_array_equal(sc, gsc)
