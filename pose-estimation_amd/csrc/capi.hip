@@ -312,6 +312,14 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
     // tile width along Cout
     int tn = d.tile_n;
     if (tn == 0) tn = d.cout <= 32 ? 32 : (d.cout <= 64 ? 64 : (d.cout % 128 == 0 ? 128 : (d.cout % 96 == 0 ? 96 : 128)));
+    if (d.tile_n == 0) {
+      // few pixels (single frames): narrower N tiles put more blocks on the chip; the K loop is latency-bound
+      // per block, so the frame latency falls although every patch is then fetched by several blocks
+      static const char* small_env = getenv("POSEHIP_SMALL_BATCH_TILE_N");
+      const int small_tn = small_env ? atoi(small_env) : 32;  // 0 disables
+      const long long m_tiles = ((long long)batch * in.d.height * in.d.width + 255) / 256;
+      if (small_tn && m_tiles * ((d.cout + tn - 1) / tn) < 128 && tn > small_tn) tn = small_tn;
+    }
     if (tn != 32 && tn != 64 && tn != 96 && tn != 128) {
       ph_set_error("ph_net_build: op %d: tile_n %d not in {32,64,96,128}", i, tn);
       return -1;
@@ -439,7 +447,7 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
           a.d.act > PH_ACT_RELU || a.d.n_dst != 1 || a.d.f32_coff >= 0 || a.d.dst_coff[0] != 0 || a.d.pool)
         continue;
       if (b.d.kh != 3 || b.d.in_buf != a.d.dst_buf[0] || b.d.in_coff != 0 || b.d.cin_read != 64 || b.d.cout > 64 ||
-          b.nrep != 2 || (b.variant != 4 && b.variant != 5) || b.cp.debug)
+          (b.variant != 4 && b.variant != 5) || b.cp.debug)
         continue;
       bool shared = false;
       for (int j = 0; j < n_ops; j++)
@@ -461,6 +469,7 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       if (q.Kpad0 < 96 || !ph_conv_halo_plan(q, 3, false)) continue;
       b.cp = q;
       b.variant = 5;
+      b.nrep = 2;  // the stem instantiation is 64 channels wide
       a.skip = true;
     }
   }
