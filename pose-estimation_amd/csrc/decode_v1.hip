@@ -160,37 +160,91 @@ __global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __
     s_sm[i] = inside ? t[0] * 0.5f + (t[-V1_TILE_W] + t[V1_TILE_W]) * 0.25f : -INFINITY;
   }
   __syncthreads();
-  // 4. runs: the thread on a run's first pixel walks it.  Slots are reserved per BLOCK (LDS counter, then one
-  //    global atomicAdd): a per-run global atomic on the map's single counter serialises whole blobs.
+  // 4. runs, one wave per tile row (16 rows = 16 waves): lane l holds pixels l, l+64, l+128, l+192 of the row, so
+  //    a ballot per 64-pixel word gives the row's mask as four 64-bit words.  The best pixel of every run (max
+  //    value, first position on ties -- what a left-to-right walk with `>` finds) comes from a segmented max-scan
+  //    (6 shuffle steps per word, carry across words); the lane on a run's LAST pixel emits it, its first pixel
+  //    found by bit scans.  Slots are reserved per BLOCK (LDS counter, then one global atomicAdd).
+  static_assert(V1_TILE_W == 256 && V1_TILE_H * 64 == V1_RUN_THREADS, "one wave per 256-pixel tile row");
   __shared__ int s_cnt, s_base;
   if (tid == 0) s_cnt = 0;
   __syncthreads();
   int* cnt = n_runs + (size_t)b * n_parts + part;
   V1Run* out = runs + ((size_t)b * n_parts + part) * run_cap;
-  constexpr int PER_T = V1_TILE_H * V1_TILE_W / V1_RUN_THREADS;
-  V1Run mine[PER_T];
-  int myslot[PER_T];
+  const int r = tid >> 6, l = tid & 63;
+  const float* row = s_sm + r * V1_TILE_W;
+  float v[4], sv[4];
+  int sp[4];
+  unsigned long long mw[4];
 #pragma unroll
-  for (int k = 0; k < PER_T; k++) {
-    const int i = tid + k * V1_RUN_THREADS;
-    const int r = i / V1_TILE_W, c = i - r * V1_TILE_W;
-    const float* row = s_sm + r * V1_TILE_W;
-    myslot[k] = -1;
-    if (row[c] > thr && (c == 0 || !(row[c - 1] > thr))) {
-      float best = row[c];
-      int bx = c, e = c;
-      while (e + 1 < V1_TILE_W && row[e + 1] > thr) {
-        e++;
-        if (row[e] > best) {
-          best = row[e];
-          bx = e;
+  for (int k = 0; k < 4; k++) {
+    v[k] = row[64 * k + l];
+    mw[k] = __ballot(v[k] > thr);
+  }
+  float cv = 0.f;   // scan value / position carried out of the previous word (its lane 63)
+  int cp = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const bool on = (mw[k] >> l) & 1;
+    const bool prev_on = l > 0 ? ((mw[k] >> (l - 1)) & 1) : (k > 0 && (mw[k - 1] >> 63) & 1);
+    float x = v[k];
+    int px = 64 * k + l;
+    bool f = !on || !prev_on || l == 0;   // segment head inside this word (word-crossing runs: carry below)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float ox = __shfl_up(x, d);
+      const int op = __shfl_up(px, d);
+      const int of = __shfl_up((int)f, d);
+      if (l >= d && !f) {
+        if (ox >= x) {  // the earlier pixel wins ties
+          x = ox;
+          px = op;
         }
+        f = of;
+      }
+    }
+    // lanes of the run that continues from the previous word: merge its carried best
+    if (k > 0 && on && ((mw[k - 1] >> 63) & 1)) {
+      const unsigned long long z = ~mw[k];
+      const int first_zero = z ? __ffsll((long long)z) - 1 : 64;
+      if (l < first_zero && cv >= x) {
+        x = cv;
+        px = cp;
+      }
+    }
+    sv[k] = x;
+    sp[k] = px;
+    cv = __shfl(x, 63);
+    cp = __shfl(px, 63);
+  }
+  V1Run mine[4];
+  int myslot[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    myslot[k] = -1;
+    const bool on = (mw[k] >> l) & 1;
+    const bool next_on = l < 63 ? ((mw[k] >> (l + 1)) & 1) : (k < 3 && (mw[k + 1] & 1));
+    if (on && !next_on) {  // last pixel of a run: its first pixel = one past the nearest zero to the left
+      int kk = k;
+      unsigned long long below = l ? (~mw[k]) & ((1ull << l) - 1ull) : 0ull;
+      int start;
+      while (true) {
+        if (below) {
+          start = 64 * kk + (63 - __clzll((long long)below)) + 1;
+          break;
+        }
+        if (kk == 0) {
+          start = 0;
+          break;
+        }
+        kk--;
+        below = ~mw[kk];
       }
       mine[k].y = y0 + r;
-      mine[k].xs = x0 + c;
-      mine[k].xe = x0 + e;
-      mine[k].bx = x0 + bx;
-      mine[k].best = best;
+      mine[k].xs = x0 + start;
+      mine[k].xe = x0 + 64 * k + l;
+      mine[k].bx = x0 + sp[k];
+      mine[k].best = sv[k];
       myslot[k] = atomicAdd(&s_cnt, 1);
     }
   }
@@ -198,7 +252,7 @@ __global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __
   if (tid == 0) s_base = s_cnt ? atomicAdd(cnt, s_cnt) : 0;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < PER_T; k++)
+  for (int k = 0; k < 4; k++)
     if (myslot[k] >= 0) {
       const int slot = s_base + myslot[k];
       if (slot < run_cap) out[slot] = mine[k];
