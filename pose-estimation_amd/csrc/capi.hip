@@ -316,9 +316,10 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       // few pixels (single frames): narrower N tiles put more blocks on the chip; the K loop is latency-bound
       // per block, so the frame latency falls although every patch is then fetched by several blocks
       static const char* small_env = getenv("POSEHIP_SMALL_BATCH_TILE_N");
-      const int small_tn = small_env ? atoi(small_env) : 32;  // 0 disables
+      const int small_tn = small_env ? atoi(small_env) : 32;  // narrowest allowed; 0 disables
       const long long m_tiles = ((long long)batch * in.d.height * in.d.width + 255) / 256;
-      if (small_tn && m_tiles * ((d.cout + tn - 1) / tn) < 128 && tn > small_tn) tn = small_tn;
+      while (small_tn && tn > small_tn && m_tiles * ((d.cout + tn - 1) / tn) < 128)
+        tn = (tn == 128 && d.cout % 64 == 0) ? 64 : 32;   // 128 -> 64 -> 32; 96 -> 32 (no half-empty tile)
     }
     if (tn != 32 && tn != 64 && tn != 96 && tn != 128) {
       ph_set_error("ph_net_build: op %d: tile_n %d not in {32,64,96,128}", i, tn);
