@@ -318,7 +318,9 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       static const char* small_env = getenv("POSEHIP_SMALL_BATCH_TILE_N");
       const int small_tn = small_env ? atoi(small_env) : 32;  // narrowest allowed; 0 disables
       const long long m_tiles = ((long long)batch * in.d.height * in.d.width + 255) / 256;
-      while (small_tn && tn > small_tn && m_tiles * ((d.cout + tn - 1) / tn) < 128)
+      static const char* blocks_env = getenv("POSEHIP_SMALL_BATCH_BLOCKS");
+      const int min_blocks = blocks_env ? atoi(blocks_env) : 128;
+      while (small_tn && tn > small_tn && m_tiles * ((d.cout + tn - 1) / tn) < min_blocks)
         tn = (tn == 128 && d.cout % 64 == 0) ? 64 : 32;   // 128 -> 64 -> 32; 96 -> 32 (no half-empty tile)
     }
     if (tn != 32 && tn != 64 && tn != 96 && tn != 128) {
