@@ -410,8 +410,8 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
     p.in_coff = d.in_coff;
     p.NQ = batch * in.Hp() * in.Wp();
     {
-      // kernel choice: POSEHIP_CONV_KERNEL=0/2/3 forces the im2col-gather kernels, 4/5 the 3x3 halo-patch
-      // kernel (4 / 8 waves) wherever it applies
+      // kernel choice: POSEHIP_CONV_KERNEL=0 forces the im2col-gather kernel, 4/5 the 3x3 halo-patch kernel
+      // (4 / 8 waves) wherever it applies
       const char* ev = getenv("POSEHIP_CONV_KERNEL");
       // auto: halo kernel, 8-wave blocks below 128 output channels per tile (more waves hide the
       // per-step latency there), 4-wave blocks with 128-row wave tiles at 128
@@ -581,7 +581,6 @@ int ph_op_kernel(ph_ctx* c, int op, char* name, int cap) {
   else if (o.variant == 4 || o.variant == 5)
     snprintf(name, cap, "conv3x3_halo_kernel<%d, %d, %s, false, 9>", o.nrep, o.variant == 5 ? 4 : 2,
              o.cp.debug ? "true" : "false");
-  else if (o.variant == 2 || o.variant == 3) snprintf(name, cap, "conv_igemm_s_kernel<%d, %d>", o.nrep, o.variant);
   else snprintf(name, cap, "conv_igemm_kernel<%d>", o.nrep);
   return 0;
 }

@@ -259,258 +259,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const PhConvParams
   }
 }
 
-// ---------------------------------------------------------------------------
-// Streaming variant: same 128 x BN block tile and 2x2 wave grid, but BK = 32 per
-// LDS stage (one MFMA K step), so a block holds only NSTAGE * (8 + BN/16) KB of LDS
-// and FOUR blocks are co-resident per CU (128 VGPRs): the memory phases of one
-// block (first fill, epilogue stores) overlap the MFMA phases of the others, and
-// the 943-tile layers of the 46x82 stages fit the 1024 block slots in one round.
-// LDS rows are 64 B; the fragment reads are made conflict-free by storing k-chunk
-// c of row r in slot c ^ ((-(r >> 2)) & 3) (applied on the LDS-DMA source address).
-// The MFMA operands are swapped (weights as A, pixels as B) so that a lane ends up
-// with 4 consecutive channels of one pixel: 8-byte LDS stores in the epilogue and
-// pixel-contiguous fp32 NCHW stores.  Bias / PReLU slope / per-row pixel
-// coordinates are staged in LDS once per block (no integer division after the
-// prologue).
-// ---------------------------------------------------------------------------
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-template <int NREP, int NSTAGE>
-__global__ __launch_bounds__(256, 4) void conv_igemm_s_kernel(const PhConvParams p) {
-  constexpr int SBK = 32;
-  constexpr int BN = 32 * NREP;
-  constexpr int B_INSTR = (BN + 63) / 64;       // 64 weight rows per staging instruction
-  constexpr int A_BYTES = BM * SBK * 2;         // 8 KB
-  constexpr int B_BYTES = B_INSTR * 64 * SBK * 2;
-  constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int LPS = 2 + B_INSTR;              // LDS-DMA instructions per wave per stage
-  constexpr int CROWB = BN * 2 + 16;            // bytes per staged output row
-  static_assert(64 * CROWB <= NSTAGE * STAGE, "epilogue half tile must fit the ring");
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  float* s_bias = (float*)(lds + NSTAGE * STAGE);
-  float* s_slope = s_bias + 128;
-  int2* s_row = (int2*)(s_slope + 128);         // per tile row: {batch index or -1, y << 16 | x}
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
-  const bool dbg_t = (p.debug & 8) != 0;
-  long long t0 = 0, t1 = 0, t2 = 0, tw = 0;
-  if (dbg_t) t0 = clock64();
-
-  const unsigned nblk = gridDim.x;
-  const unsigned bid = blockIdx.x;
-  const unsigned xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-  const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int mt = logical / p.n_ntiles;
-  const int nt = logical - mt * p.n_ntiles;
-  const int m0 = mt * BM;
-  const int n0 = nt * BN;
-
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-
-  // bias / slope -> LDS (issued first: LDS-DMA completes in order, so the first
-  // stage wait covers it)
-  {
-    const float* src = (wave < 2 ? p.bias : p.slope) + n0 + (wave & 1) * 64 + lane;
-    float* dst = (wave < 2 ? s_bias : s_slope) + (wave & 1) * 64;
-    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 4, 0, 0);
-  }
-
-  // ---- per-thread staging addresses ---------------------------------------
-  const int lrow = tid >> 2;                                  // 0..63
-  const int chunk = (tid & 3) ^ ((4 - ((tid >> 4) & 3)) & 3); // source 16-B k-chunk (swizzled)
-  const int HW = p.H * p.W;
-  unsigned a_off[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int mr = m0 + i * 64 + lrow;
-    const int m = mr < p.M ? mr : p.M - 1;
-    const int b = m / HW;
-    const int rem = m - b * HW;
-    const int y = rem / p.W;
-    const int x = rem - y * p.W;
-    a_off[i] = (unsigned)p.in_org + (unsigned)((b * p.in_Hp + y) * p.in_Wp + x) * (unsigned)p.in_Cs;
-    if ((tid & 3) == 0) s_row[i * 64 + lrow] = make_int2(mr < p.M ? b : -1, (y << 16) | x);
-  }
-  unsigned w_off[B_INSTR];
-#pragma unroll
-  for (int i = 0; i < B_INSTR; i++) {
-    int n = n0 + i * 64 + lrow;
-    n = n < p.cout_pad ? n : p.cout_pad - 1;  // rows past the tile: any valid row, never used
-    w_off[i] = (unsigned)n * (unsigned)p.Kpad;
-  }
-
-  auto stage = [&](int kt, int slot) {
-    const int k = kt * SBK + chunk * 8;
-    unsigned off = 0;
-    if (k < p.K) {
-      const unsigned tap = ph_div((unsigned)k, p.magic_cin, (unsigned)p.cin_read);
-      const unsigned c = (unsigned)k - tap * (unsigned)p.cin_read;
-      const unsigned kh = ph_div(tap, p.magic_kw, (unsigned)p.KW);
-      const unsigned kw = tap - kh * (unsigned)p.KW;
-      off = (kh * (unsigned)p.in_Wp + kw) * (unsigned)p.in_Cs + c;
-    }
-    char* sa = lds + slot * STAGE + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-      __builtin_amdgcn_global_load_lds((glb_void*)(p.in + a_off[i] + off), (lds_void*)(sa + i * 4096), 16, 0, 0);
-    char* sb = lds + slot * STAGE + A_BYTES + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < B_INSTR; i++)
-      __builtin_amdgcn_global_load_lds((glb_void*)(p.wt + w_off[i] + k), (lds_void*)(sb + i * 4096), 16, 0, 0);
-  };
-
-  // ---- fragment read addresses: row (lane & 15) of a 16-row block, k-chunk lane >> 4
-  const int fr = lane & 15, fq = lane >> 4;
-  const int fslot = fq ^ ((4 - ((fr >> 2) & 3)) & 3);
-  const int a_rd = (wm * 64 + fr) * 64 + fslot * 16;
-  const int b_rd = A_BYTES + (wn * (BN / 2) + fr) * 64 + fslot * 16;
-
-  f32x4 acc[4][NREP];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < NREP; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- main loop: one barrier per 32-deep K step ---------------------------
-  const int nk = p.Kpad / SBK;
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; s++)
-    if (s < nk) stage(s, s);
-  if (dbg_t) t1 = clock64();
-  int slot = 0;
-  for (int kt = 0; kt < nk; kt++) {
-    long long ta = 0;
-    if (dbg_t) ta = clock64();
-    // K step kt has landed when at most the later-issued stages are outstanding
-    if (NSTAGE == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // ... for every wave; and slot (kt-1) % NSTAGE is free again
-    asm volatile("" ::: "memory");
-    if (dbg_t) tw += clock64() - ta;
-    {
-      const int kn = kt + NSTAGE - 1;
-      int sn = slot + NSTAGE - 1;
-      sn = sn >= NSTAGE ? sn - NSTAGE : sn;
-      if (kn < nk) stage(kn, sn);
-    }
-    const char* base = lds + slot * STAGE;
-    bf16x8 af[4], bfr[NREP];
-#pragma unroll
-    for (int i = 0; i < 4; i++) af[i] = *(const bf16x8*)(base + a_rd + i * 1024);
-#pragma unroll
-    for (int j = 0; j < NREP; j++) bfr[j] = *(const bf16x8*)(base + b_rd + j * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < NREP; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    slot = slot + 1 == NSTAGE ? 0 : slot + 1;
-  }
-  if (dbg_t) t2 = clock64();
-
-  // ---- epilogue --------------------------------------------------------------
-  // swapped operands: acc[i][j][e] = pixel (wm*64 + i*16 + fr), channel (wn*BN/2 + j*16 + fq*4 + e)
-  const int cbase = wn * (BN / 2) + fq * 4;
-#pragma unroll
-  for (int j = 0; j < NREP; j++) {
-    const f32x4 bv = *(const f32x4*)(s_bias + cbase + j * 16);
-    f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.act == 2) sv = *(const f32x4*)(s_slope + cbase + j * 16);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        float v = acc[i][j][e] + bv[e];
-        if (p.act) v = v > 0.f ? v : v * sv[e];
-        acc[i][j][e] = v;
-      }
-  }
-
-  if (p.f32_out) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int2 ri = s_row[wm * 64 + i * 16 + fr];
-      if (ri.x >= 0) {
-        const int rem = (ri.y >> 16) * p.W + (ri.y & 0xffff);
-        float* o = p.f32_out + ((size_t)ri.x * p.f32_C + p.f32_coff + n0 + cbase) * HW + rem;
-#pragma unroll
-        for (int j = 0; j < NREP; j++)
-#pragma unroll
-          for (int e = 0; e < 4; e++)
-            if (n0 + cbase + j * 16 + e < p.cout) o[(size_t)(j * 16 + e) * HW] = acc[i][j][e];
-      }
-    }
-  }
-
-  if (p.n_dst > 0) {
-    constexpr int VPR = BN / 8;                // 16-byte vectors per pixel row
-    const int nvalid = p.cout - n0;            // valid channels in this N tile
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      __syncthreads();  // fragment reads of the last K step / store reads of the first half are done
-      if (wm == half) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int j = 0; j < NREP; j++) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = (bf16)acc[i][j][e];
-            *(bf16x4*)(lds + (i * 16 + fr) * CROWB + (cbase + j * 16) * 2) = o;
-          }
-      }
-      __syncthreads();
-      for (int v = tid; v < 64 * VPR; v += NTHREADS) {
-        const int row = v / VPR;
-        const int cv = (v - row * VPR) * 8;
-        const int2 ri = s_row[half * 64 + row];
-        if (ri.x < 0 || cv >= nvalid) continue;
-        const int y = ri.y >> 16, x = ri.y & 0xffff;
-        const char* sp = lds + row * CROWB + cv * 2;
-        const u32x4 val = *(const u32x4*)sp;
-        for (int d = 0; d < p.n_dst; d++) {
-          const PhDst& ds = p.dst[d];
-          bf16* o = ds.base + (size_t)ds.org + ((size_t)(ri.x * ds.Hp + y) * ds.Wp + x) * ds.Cs + n0 + cv;
-          if (cv + 8 <= nvalid) {
-            *(u32x4*)o = val;
-          } else {
-            for (int e = 0; e < nvalid - cv; e++) o[e] = ((const bf16*)sp)[e];
-          }
-        }
-      }
-    }
-  }
-  if (dbg_t) {
-    __syncthreads();
-    if (tid == 0) {
-      const long long t3 = clock64();
-      atomicAdd(&ph_conv_dbg[0], (unsigned long long)(t1 - t0));
-      atomicAdd(&ph_conv_dbg[1], (unsigned long long)(t2 - t1));
-      atomicAdd(&ph_conv_dbg[2], (unsigned long long)(t3 - t2));
-      atomicAdd(&ph_conv_dbg[3], (unsigned long long)tw);
-      atomicAdd(&ph_conv_dbg[4], 1ull);
-    }
-  }
-}
-
-template <int NREP, int NSTAGE>
-static int launch_s(const PhConvParams& p, hipStream_t stream) {
-  constexpr int BN = 32 * NREP;
-  constexpr int STAGE = BM * 64 + ((BN + 63) / 64) * 64 * 64;
-  constexpr int LDS = NSTAGE * STAGE + 2048;
-  static int attr[PH_MAX_DEVICES];
-  if (ph_ensure_lds((const void*)conv_igemm_s_kernel<NREP, NSTAGE>, LDS, attr)) return -1;
-  PhConvParams q = p;
-  q.n_mtiles = (p.M + BM - 1) / BM;
-  q.n_ntiles = (p.cout + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_igemm_s_kernel<NREP, NSTAGE>), dim3(q.n_mtiles * q.n_ntiles), dim3(NTHREADS), LDS, stream, q);
-  PH_CHECK(hipGetLastError());
-  return 0;
-}
 
 // ---------------------------------------------------------------------------
 // 3x3 halo-patch kernel.  The im2col gather above re-reads every input pixel 9x
@@ -1155,8 +904,8 @@ static int launch_halo_sel(const PhConvParams& p, int mw, hipStream_t stream) {
   return p.debug ? launch_halo<NREP, 2, true>(p, stream) : launch_halo<NREP, 2, false>(p, stream);
 }
 
-// variant 0: BK 64, 2 LDS stages, 2 blocks/CU.  variant 2 / 3: BK 32, 2 / 3 LDS stages, 4 / 3 blocks/CU.
-// variant 4: 3x3 halo-patch kernel (geometry from ph_conv_halo_plan).
+// variant 0: im2col-gather kernel (any odd kernel size / channel count).  variant 4 / 5: 3x3 halo-patch kernel with
+// 4 / 8 waves, 6: 1x1 through the same pipeline (geometry from ph_conv_halo_plan).
 int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t stream) {
   if (p.stem) return launch_halo_stem(p, stream);
   if (variant == 6) {  // 1x1 through the halo pipeline
@@ -1175,19 +924,6 @@ int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t str
       case 2: return launch_halo_sel<2>(p, mw, stream);
       case 3: return launch_halo_sel<3>(p, mw, stream);
       case 4: return launch_halo_sel<4>(p, mw, stream);
-      default: ph_set_error("ph_launch_conv: bad nrep %d", nrep); return -1;
-    }
-  }
-  if (variant == 2 || variant == 3) {
-    switch (nrep * 10 + variant) {
-      case 12: return launch_s<1, 2>(p, stream);
-      case 22: return launch_s<2, 2>(p, stream);
-      case 32: return launch_s<3, 2>(p, stream);
-      case 42: return launch_s<4, 2>(p, stream);
-      case 13: return launch_s<1, 3>(p, stream);
-      case 23: return launch_s<2, 3>(p, stream);
-      case 33: return launch_s<3, 3>(p, stream);
-      case 43: return launch_s<4, 3>(p, stream);
       default: ph_set_error("ph_launch_conv: bad nrep %d", nrep); return -1;
     }
   }
