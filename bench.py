@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--per-op", action="store_true", help="print a per-op time table to stderr")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (engines / HIP streams)")
+    ap.add_argument("--frame-size", type=str, default=f"{NET_H}x{NET_W}",
+                    help="HxW of the source frames (1080x1920 = BASELINE configs[4]: 1080p stream, '-1x368' "
+                         "net resolution, keypoints scaled back to source pixels); default = configs[1]")
     ap.add_argument("--h2d", action="store_true",
                     help="frames start in pinned HOST memory and are copied in every step (PCIe-inclusive "
                          "rate for DESIGN.md; never the headline value)")
@@ -106,7 +109,9 @@ def main():
     conv_mask = np.array([o["type"] == _ffi.PH_OP_CONV for o in plan.ops])
 
     from posehip import synth
-    frames_host = torch.from_numpy(synth.synth_frames(1000 + rank, B, NET_H, NET_W)).pin_memory()
+    src_h, src_w = (int(v) for v in args.frame_size.lower().split("x"))
+    kp_scale = max(src_h / NET_H, src_w / NET_W)   # keep-aspect resize of the native flavour, inverted
+    frames_host = torch.from_numpy(synth.synth_frames(1000 + rank, B, src_h, src_w)).pin_memory()
     J = BODY_25.n_parts
     bufs = []
     for k in range(S):
@@ -142,7 +147,7 @@ def main():
                 d["frames"].copy_(frames_host, non_blocking=True)
         e.preprocess(d["frames"], _ffi.PH_PRE_NATIVE)
         e.forward(B)
-        e.decode_v2_dev(BODY_25, B, NET_H, NET_W, 1.0, MAX_PEOPLE)
+        e.decode_v2_dev(BODY_25, B, NET_H, NET_W, kp_scale, MAX_PEOPLE)
         # results to pinned host memory (rank-local) ...
         e.decode_v2_results(d["n"], d["kp"], d["sc"])
         if world > 1 and backend == "nccl":  # ... and one RCCL all_gather of the padded tensors (rank 0 keeps it)
@@ -187,7 +192,7 @@ def main():
     for _ in range(n_prof):
         eng.preprocess(bufs[0]["frames"], _ffi.PH_PRE_NATIVE)
         eng.forward_timed(B, wait=False)
-        eng.decode_v2_dev(BODY_25, B, NET_H, NET_W, 1.0, MAX_PEOPLE)
+        eng.decode_v2_dev(BODY_25, B, NET_H, NET_W, kp_scale, MAX_PEOPLE)
         tstreams[0].synchronize()
         ms = eng.forward_times()
         conv_ms_total += float(ms[conv_mask].sum())
@@ -244,7 +249,7 @@ def main():
             "config": {"workload": "BODY_25 batch-32 frames 368x656 per GPU: preprocess + backbone + "
                                    "PAF/heatmap stages + upsample/NMS + PAF matching + assembly "
                                    "(BASELINE configs[1])",
-                       "batch_per_gpu": B, "net_resolution": f"{NET_W}x{NET_H}", "weights": "random He-normal",
+                       "batch_per_gpu": B, "net_resolution": f"{NET_W}x{NET_H}", "source_frames": f"{src_w}x{src_h}", "weights": "random He-normal",
                        "frames": "pinned host, H2D every step" if args.h2d else "resident in HBM",
                        "batches_in_flight_per_gpu": S,
                        "parallelism": f"frame-parallel x{world}, RCCL keypoint all_gather"},
