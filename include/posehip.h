@@ -156,6 +156,17 @@ int ph_decode_v2_dev(ph_ctx* ctx, const ph_v2_model* model, int B, int Ht, int W
  * (dst_on_device=0) or device memory (dst_on_device=1, e.g. the send buffer of
  * the RCCL keypoint gather).  Any pointer may be NULL. */
 int ph_decode_v2_results(ph_ctx* ctx, int32_t* n_people, float* keypoints, float* scores, int dst_on_device);
+/* Per-person post-processing of the LAST ph_decode_v2(_dev) results, on the device keypoints (no D2H first):
+ *  bbox  [B][max_people][4] f32 (u_min, v_min, u_max, v_max) over the `torso_ids` joints with score != 0
+ *        (degenerate side -> +1, none -> 0,0,1,1): PyOpenPoseNativeBase.pose_bounding_box,
+ *        openpose/native/python/skeleton.py:89-113; NULL = skip.
+ *  kp3d  [B][max_people][n_parts][3] f64: mean of the u16 depth patch [y-po, y+po) x [x-po, x+po) and pinhole
+ *        back-projection, scaled by depth_scale: get_3d_skeleton, skeleton.py:130-160; NULL = skip.
+ *        depth: u16 [B][Hd][Wd], host or device.  Rows past n_people[b] are zero.  Synchronises the stream. */
+int ph_pose_post(ph_ctx* ctx, int B, int max_people, int n_parts, const int32_t* torso_ids, int n_torso, float* bbox,
+                 const uint16_t* depth, int depth_on_device, int Hd, int Wd, double fx, double fy, double cx, double cy,
+                 double depth_scale, int patch_offset, double* kp3d);
+
 /* test/debug: per-limb connections of the last decode.  n_conn i32 [B][n_pairs],
  * conn_idx i32 [B][n_pairs][max_peaks][2] (upstream peak indices part*3*(max_peaks+1)
  * + i*3 + 2), conn_score f32 [B][n_pairs][max_peaks]; any pointer may be NULL. */

@@ -16,6 +16,11 @@
 
 int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t stream);
 bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32);
+int ph_launch_torso_bbox(const float* kp, const int* n_people, int B, int maxp, int J, const int* ids, int n_ids,
+                         float* out, hipStream_t stream);
+int ph_launch_lift3d(const float* kp, const int* n_people, int B, int maxp, int J, const uint16_t* depth, int Hd,
+                     int Wd, double fx, double fy, double cx, double cy, double depth_scale, int po, double* out,
+                     hipStream_t stream);
 int ph_launch_maxpool(const bf16* in, bf16* out, int B, int H, int W, int C, int in_Hp, int in_Wp, int in_Cs,
                       int in_org, int oH, int oW, int out_Hp, int out_Wp, int out_Cs, int out_org,
                       hipStream_t stream);
@@ -81,6 +86,9 @@ struct ph_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev1[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> op_ev;
+  // ph_pose_post scratch (grown on demand)
+  void* post = nullptr;
+  size_t post_bytes = 0;
 };
 
 static uint16_t f32_to_bf16(float f) {
@@ -177,6 +185,7 @@ void ph_destroy(ph_ctx* c) {
   if (c->net_out) (void)hipFree(c->net_out);
   if (c->inj_out) (void)hipFree(c->inj_out);
   if (c->frames) (void)hipFree(c->frames);
+  if (c->post) (void)hipFree(c->post);
   for (int i = 0; i < 4; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -779,6 +788,64 @@ int ph_decode_v2_results(ph_ctx* c, int32_t* n_people, float* keypoints, float* 
   if (n_people) PH_CHECK(hipMemcpyAsync(n_people, c->v2.n_people, c->v2sz.n_people, k, s));
   if (keypoints) PH_CHECK(hipMemcpyAsync(keypoints, c->v2.keypoints, c->v2sz.keypoints, k, s));
   if (scores) PH_CHECK(hipMemcpyAsync(scores, c->v2.scores, c->v2sz.scores, k, s));
+  return 0;
+}
+
+int ph_pose_post(ph_ctx* c, int B, int max_people, int n_parts, const int32_t* torso_ids, int n_torso, float* bbox,
+                 const uint16_t* depth, int depth_on_device, int Hd, int Wd, double fx, double fy, double cx, double cy,
+                 double depth_scale, int patch_offset, double* kp3d) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!c->v2.n_people || B < 1 || max_people < 1 || n_parts < 1 ||
+      (size_t)B * max_people * n_parts * 3 * sizeof(float) > c->v2sz.keypoints) {
+    ph_set_error("ph_pose_post: no V2 decode of %d x %d x %d keypoints has run", B, max_people, n_parts);
+    return -1;
+  }
+  if (bbox && (!torso_ids || n_torso < 1 || n_torso > 64)) {
+    ph_set_error("ph_pose_post: bbox needs 1..64 torso ids");
+    return -1;
+  }
+  for (int k = 0; bbox && k < n_torso; k++)
+    if (torso_ids[k] < 0 || torso_ids[k] >= n_parts) {
+      ph_set_error("ph_pose_post: torso id %d out of range", torso_ids[k]);
+      return -1;
+    }
+  if (kp3d && (!depth || Hd < 1 || Wd < 1 || patch_offset < 0 || fx == 0.0 || fy == 0.0)) {
+    ph_set_error("ph_pose_post: the 3-D lift needs a depth image and non-zero focal lengths");
+    return -1;
+  }
+  const size_t n_bb = (size_t)B * max_people * 4 * sizeof(float);
+  const size_t n_3d = (size_t)B * max_people * n_parts * 3 * sizeof(double);
+  const size_t n_dp = (kp3d && !depth_on_device) ? (size_t)B * Hd * Wd * sizeof(uint16_t) : 0;
+  const size_t off_bb = 256, off_3d = off_bb + ((n_bb + 255) & ~(size_t)255), off_dp = off_3d + ((n_3d + 255) & ~(size_t)255);
+  const size_t need = off_dp + n_dp;
+  if (need > c->post_bytes) {
+    if (c->post) PH_CHECK(hipFree(c->post));
+    c->post = nullptr;
+    c->post_bytes = 0;
+    PH_CHECK(hipMalloc(&c->post, need));
+    c->post_bytes = need;
+  }
+  char* base = (char*)c->post;
+  hipStream_t s = c->stream;
+  if (bbox) {
+    PH_CHECK(hipMemcpyAsync(base, torso_ids, n_torso * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (ph_launch_torso_bbox(c->v2.keypoints, c->v2.n_people, B, max_people, n_parts, (const int*)base, n_torso,
+                             (float*)(base + off_bb), s))
+      return -1;
+    PH_CHECK(hipMemcpyAsync(bbox, base + off_bb, n_bb, hipMemcpyDeviceToHost, s));
+  }
+  if (kp3d) {
+    const uint16_t* dd = depth;
+    if (!depth_on_device) {
+      PH_CHECK(hipMemcpyAsync(base + off_dp, depth, n_dp, hipMemcpyHostToDevice, s));
+      dd = (const uint16_t*)(base + off_dp);
+    }
+    if (ph_launch_lift3d(c->v2.keypoints, c->v2.n_people, B, max_people, n_parts, dd, Hd, Wd, fx, fy, cx, cy,
+                         depth_scale, patch_offset, (double*)(base + off_3d), s))
+      return -1;
+    PH_CHECK(hipMemcpyAsync(kp3d, base + off_3d, n_3d, hipMemcpyDeviceToHost, s));
+  }
+  PH_CHECK(hipStreamSynchronize(s));
   return 0;
 }
 

@@ -69,6 +69,8 @@ SYMBOLS = {
     "ph_forward_times": (C.c_int, [_vp, _fp]),
     "ph_op_flops": (C.c_double, [_vp, C.c_int]),
     "ph_op_kernel": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int]),
+    "ph_pose_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                               C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _vp]),
     "ph_get_net_out": (C.c_int, [_vp, C.c_int, _vp]),
     "ph_net_out_dev": (_vp, [_vp]),
     "ph_set_net_out": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -300,9 +300,12 @@ class PyOpenPoseNativeBase:
         H, W = depth_img.shape
         joints3d = []
         for x, y, _ in skeleton:
+            # float64 from here on (what the reference computes under NumPy < 2 promotion; also what
+            # Engine.pose_post / ph_pose_post computes on the device)
+            x, y = float(x), float(y)
             patch = depth_img[max(0, int(y - patch_offset)):min(H, int(y + patch_offset)),
                               max(0, int(x - patch_offset)):min(W, int(x + patch_offset))]
-            depth_avg = np.nanmean(patch)
+            depth_avg = float(np.nanmean(patch)) if patch.size else float("nan")
             x3d = (x - cx) / fx * depth_avg
             y3d = (y - cy) / fy * depth_avg
             joints3d.append([x3d * depth_scale, y3d * depth_scale, depth_avg * depth_scale])

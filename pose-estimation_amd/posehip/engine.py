@@ -181,6 +181,37 @@ class Engine:
                                                   C.c_void_p(keypoints.data_ptr()), C.c_void_p(scores.data_ptr()),
                                                   on_dev), "ph_decode_v2_results")
 
+    def pose_post(self, B, max_people, n_parts, torso_ids=None, depth=None, intr=None, depth_scale=1e-3,
+                  patch_offset=2):
+        """Torso boxes and / or 3-D lift of the last decode_v2(_dev) results, computed on the device keypoints.
+        depth: u16 [B,Hd,Wd] NumPy array or CUDA tensor; intr = (fx, fy, cx, cy).
+        -> (bbox f32 [B,max_people,4] | None, kp3d f64 [B,max_people,n_parts,3] | None)"""
+        bbox = kp3d = ids = None
+        if torso_ids is not None:
+            ids = np.ascontiguousarray(torso_ids, np.int32)
+            bbox = np.zeros((B, max_people, 4), np.float32)
+        dptr, on_dev, Hd, Wd = None, 0, 0, 0
+        fx = fy = cx = cy = 0.0
+        if depth is not None:
+            if isinstance(depth, np.ndarray):
+                depth = np.ascontiguousarray(depth, np.uint16)
+                dptr = _ptr(depth)
+            else:
+                if not depth.is_cuda or not depth.is_contiguous() or depth.element_size() != 2:
+                    raise ValueError("device depth must be a contiguous CUDA 16-bit tensor [B,H,W]")
+                dptr, on_dev = C.c_void_p(depth.data_ptr()), 1
+            if depth.ndim != 3 or depth.shape[0] < B:
+                raise ValueError(f"depth must be [B>={B},H,W], got {tuple(depth.shape)}")
+            Hd, Wd = int(depth.shape[1]), int(depth.shape[2])
+            fx, fy, cx, cy = (float(v) for v in intr)
+            kp3d = np.zeros((B, max_people, n_parts, 3), np.float64)
+        _ffi.check(self._lib.ph_pose_post(self._ctx, int(B), int(max_people), int(n_parts),
+                                          _ptr(ids) if ids is not None else None, len(ids) if ids is not None else 0,
+                                          _ptr(bbox) if bbox is not None else None, dptr, on_dev, Hd, Wd, fx, fy, cx, cy,
+                                          float(depth_scale), int(patch_offset),
+                                          _ptr(kp3d) if kp3d is not None else None), "ph_pose_post")
+        return bbox, kp3d
+
     def decode_v2_connections(self, model, B):
         """Test/debug: per-limb connection lists of the last decode."""
         _, model = self._v2(model)

@@ -5,7 +5,7 @@ operation order, -ffp-contract=off)."""
 import numpy as np
 import pytest
 
-from posehip import synth
+from posehip import _ffi, synth
 from posehip.tables import BODY_25, COCO_18
 
 pytestmark = pytest.mark.gpu
@@ -90,3 +90,33 @@ def test_non_x8_target_and_errors(engine):
     engine.set_net_out(np.zeros((1, 30, 46, 82), np.float32))
     with pytest.raises(PosehipError):
         engine.decode_v2(BODY_25, 1, 368, 656)   # too few channels for BODY_25
+
+
+def test_pose_post_matches_oracle_bit_exact(engine):
+    """torso boxes (fp32) and depth lift (fp64) computed on the device keypoints of the last decode
+    equal oracle/post_v2.py bit for bit, for host and device depth images."""
+    import torch
+    from oracle import post_v2
+    from posehip import synth
+    from posehip.tables import BODY_25, TORSO_IDS
+    B, hs, ws = 3, 46, 82
+    net = np.stack([synth.synth_net_output(900 + i, [4, 0, 7][i], BODY_25, hs, ws) for i in range(B)])
+    engine.set_net_out(net)
+    res, ex = engine.decode_v2(BODY_25, B, hs * 8, ws * 8, 1080 / 368, 128)
+    rng = np.random.default_rng(5)
+    depth = rng.integers(300, 6000, (B, 1080, 1920), dtype=np.uint16)
+    intr = (910.5, 911.25, 958.7, 541.3)
+    for dev_depth in (False, True):
+        d = torch.from_numpy(depth.view(np.int16)).cuda() if dev_depth else depth
+        bbox, kp3d = engine.pose_post(B, 128, BODY_25.n_parts, TORSO_IDS, d, intr, 1e-3, 2)
+        for b in range(B):
+            kp = res[b][0]
+            m = len(kp)
+            assert m == [4, 0, 7][b] or m > 0 or b == 1
+            np.testing.assert_array_equal(bbox[b, :m], post_v2.torso_bbox(kp, TORSO_IDS))
+            assert (bbox[b, m:] == 0).all() and (kp3d[b, m:] == 0).all()
+            for p in range(m):
+                want = post_v2.lift_3d(kp[p], depth[b], *intr, 1e-3, 2)
+                np.testing.assert_array_equal(kp3d[b, p].view(np.uint64), want.view(np.uint64))
+    with pytest.raises(_ffi.PosehipError):
+        engine.pose_post(B, 128, BODY_25.n_parts, [99], None)             # torso id out of range

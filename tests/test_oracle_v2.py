@@ -151,3 +151,26 @@ def test_golden_scenes(tag, model):
     np.testing.assert_array_equal(kp, g[tag + "_kp"])
     np.testing.assert_array_equal(sc, g[tag + "_sc"])
     np.testing.assert_array_equal(inter["peaks"][:, 0, 0].astype(np.int32), g[tag + "_peaks_n"])
+
+
+def test_post_v2_known_answers():
+    """Torso box and 3-D lift restatements (skeleton.py:89-113, 130-160): hand-computed cases."""
+    from oracle import post_v2
+    torso = [1, 2, 5, 8, 9, 12]
+    kp = np.zeros((3, 25, 3), np.float32)
+    kp[0, 1] = (10, 20, .9); kp[0, 8] = (14, 50, .8); kp[0, 2] = (5, 25, .7); kp[0, 0] = (100, 100, .9)   # nose ignored
+    kp[1, 5] = (7.5, 9.25, .5)                                    # single joint: degenerate box -> +1 on both sides
+    bb = post_v2.torso_bbox(kp, torso)                            # person 2: no torso joint -> [0,0,1,1]
+    np.testing.assert_array_equal(bb, np.array([[5, 20, 14, 50], [7.5, 9.25, 8.5, 10.25], [0, 0, 1, 1]], np.float32))
+    assert bb.dtype == np.float32
+    depth = np.arange(8 * 10, dtype=np.uint16).reshape(8, 10) * 10
+    sk = np.array([[4.7, 3.2, .9], [0.4, 0.9, .8], [50, 50, .5]], np.float32)
+    out = post_v2.lift_3d(sk, depth, fx=2.0, fy=4.0, cx=1.0, cy=2.0, depth_scale=1e-3, patch_offset=2)
+    # joint 0: rows int(1.2)=1..int(5.2)=5 -> 1..4, cols int(2.7)=2..int(6.7)=6 -> 2..5: mean of (10*(10*r+c))
+    avg0 = np.mean([10 * (10 * r + c) for r in range(1, 5) for c in range(2, 6)])
+    x, y = float(np.float32(4.7)), float(np.float32(3.2))
+    np.testing.assert_array_equal(out[0], [(x - 1.0) / 2.0 * avg0 * 1e-3, (y - 2.0) / 4.0 * avg0 * 1e-3, avg0 * 1e-3])
+    # joint 1: int(-1.6) = -1 -> 0 (truncation, not floor); rows 0..int(2.9)=2 -> 0,1; cols 0..int(2.4)=2 -> 0,1
+    avg1 = np.mean([0, 10, 100, 110])
+    assert out[1, 2] == avg1 * 1e-3
+    assert np.isnan(out[2]).all()                                 # patch outside the image: nanmean of nothing
