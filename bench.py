@@ -267,7 +267,10 @@ def main():
                                       "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
                                       "per_kernel_ms_per_step": {k: round(v[0] / n_prof, 3)
                                                                  for k, v in sorted(by_k.items())}},
-                         "decode_ms_per_step": [round(float(x) / n_prof, 3) for x in decode_ms]},
+                         "decode_ms_per_step": [round(float(x) / n_prof, 3) for x in decode_ms],
+                         # whole-pipeline view: frames/s x algorithmic FLOPs per frame against the MFMA peak of
+                         # the GPUs used (100 % = 8 700 frames/s per GPU)
+                         "end_to_end_frac_of_mfma_peak": round(fps * flops_frame / (world * MFMA_PEAK_TFLOPS * 1e12), 4)},
         }
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(net, weights, BODY_25, args.cpu_frames, 1000)
