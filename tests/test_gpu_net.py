@@ -57,6 +57,9 @@ CASES = {
     # width > 126: the 3x3 halo kernel switches from padded-linear runs to 16x16 tiles (ragged right/bottom tiles)
     "wide_tiles": (18, 150, [("conv", "c1", "image", 32, 3, "ReLU"), ("conv", "c2", "c1", 64, 3, "PReLU"),
                               ("conv", "c3", "c2", 96, 3, "ReLU"), ("conv", "out", "c3", 20, 1, None)]),
+    # single-chunk K loops: 1x1 over 32 channels (one K step), 3x3 over 32 channels (one patch, nine steps)
+    "one_chunk": (20, 36, [("conv", "a", "image", 32, 3, "ReLU"), ("conv", "b", "a", 40, 3, "PReLU"),
+                            ("conv", "c", "b", 32, 1, "ReLU"), ("conv", "out", "c", 20, 1, None)]),
     "odd_pool": (13, 19, [("conv", "c1", "image", 64, 3, "ReLU"), ("pool", "p", "c1"),
                            ("conv", "out", "p", 38, 3, None)]),
 }
