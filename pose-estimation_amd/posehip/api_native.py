@@ -461,10 +461,17 @@ class PyOpenPoseNative(PyOpenPoseNativeBase):
             datums.append(d)
         self.reset()
         self.opWrapper.emplaceAndPop(datums)
-        self.datum = datums[-1]
-        if self.datum.poseScores is None:
-            self._pose_empty = True
+        self.last_datums = datums
+        self.adopt(datums[-1])
         return [(d.poseKeypoints, d.poseScores) for d in datums]
+
+    def adopt(self, datum: Datum) -> None:
+        """Addition: make one datum of the last ``predict_batch`` the instance's current frame, so
+        the properties, ``filter_prediction`` and the writers act on it as after ``predict``."""
+        self.reset()
+        self.datum = datum
+        if datum.poseScores is None:
+            self._pose_empty = True
 
     def predict_hm(self, image: np.ndarray, hm_save_path: str) -> None:
         # raw net output -> .float file: f32 [ndim, d0..d3, data...] (:452-467)

@@ -12,6 +12,11 @@
   real_images.npz      G6: data/test/pillar_text.jpg and data/sample/COCO_val2014_000000000192.jpg
                        decoded with PIL exactly as read_color_file does (utils_rs.py:43-44: RGB -> BGR),
                        plus the oracle's cv2.resize restatement of each at 656x368 (data only).
+  callers_ref.json / callers_ref.npz   SURVEY 8f-1/8f-2 host helpers, produced BY THE REFERENCE's own
+                       openpose/native/python/{args,utils}.py (argparse/NumPy only; imported from
+                       /root/reference as a path-only package so the package __init__ is not run):
+                       every CLI flag's dest/default/type name, str2bool's truth table, get_color(_fast),
+                       and resize_tensor / cosine_distance outputs on seeded inputs.
   ref_predictions_native.txt  is a verbatim copy of the reference's only stored
                        result, data/test/output/inference_native/predictions.txt.
 """
@@ -90,8 +95,53 @@ def v1():
     np.savez_compressed(os.path.join(HERE, "v1_scenes.npz"), **out)
 
 
+def callers():
+    import importlib
+    import types
+    pkg = types.ModuleType("ref_native_python")
+    pkg.__path__ = ["/root/reference/openpose/native/python"]   # modules by path, no __init__ executed
+    sys.modules["ref_native_python"] = pkg
+    args = importlib.import_module("ref_native_python.args")
+    utils = importlib.import_module("ref_native_python.utils")
+    flags = []
+    for a in args.get_parser()._actions:
+        if a.dest == "help":
+            continue
+        flags.append({"flag": a.option_strings[0], "dest": a.dest, "default": a.default,
+                      "type": getattr(a.type, "__name__", str(a.type))})
+    truth = {}
+    for v in ("yes", "TRUE", "t", "Y", "1", "no", "False", "f", "N", "0", "maybe", ""):
+        try:
+            truth[v] = utils.str2bool(v)
+        except Exception as e:
+            truth[v] = type(e).__name__
+    meta = {"flags": flags, "str2bool": truth,
+            "get_color": [list(utils.get_color(i)) for i in range(12)],
+            "get_color_fast": [list(utils.get_color_fast(i)) for i in range(12)]}
+    with open(os.path.join(HERE, "callers_ref.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    rng = np.random.default_rng(811)
+    out = {}
+    # resize_tensor: (h, w, c) crops as create_detections makes them (tracking/utils_track.py:54-55) -> 25 x 50
+    for i, (h, w, c, x, y) in enumerate(((37, 19, 3, 25, 50), (2, 2, 1, 25, 50), (120, 61, 5, 25, 50),
+                                          (9, 33, 2, 7, 4), (50, 25, 1, 25, 50))):
+        img = rng.normal(size=(h, w, c)).astype(np.float32)
+        out[f"rt{i}_in"] = img
+        out[f"rt{i}_xy"] = np.array([x, y])
+        out[f"rt{i}_out"] = utils.resize_tensor(img, x, y)
+    a = rng.normal(size=(5, 16))
+    b = rng.normal(size=(7, 16))
+    out["cos_a"], out["cos_b"] = a, b
+    out["cos_d"] = utils.cosine_distance(a, b)
+    an = a / np.linalg.norm(a, axis=1, keepdims=True)
+    bn = b / np.linalg.norm(b, axis=1, keepdims=True)
+    out["cos_d_normalized"] = utils.cosine_distance(an, bn, True)
+    np.savez_compressed(os.path.join(HERE, "callers_ref.npz"), **out)
+
+
 if __name__ == "__main__":
     tables()
+    callers()
     v2()
     v1()
     real_images()

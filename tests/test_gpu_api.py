@@ -251,3 +251,62 @@ def test_three_engines_on_three_threads(engine):
         for (kp, sc), (gkp, gsc) in zip(r, gr):
             np.testing.assert_array_equal(kp, gkp)
             np.testing.assert_array_equal(sc, gsc)
+
+
+def test_pipeline_callers_on_the_engine(tmp_path):
+    """the reference's folder walk (inference.py:355-427), the three-thread extractor ->
+    tracker -> writer (:22-165) and the batched walk on the real engine: same CSV files either way."""
+    from PIL import Image
+    from posehip import args as ph_args
+    from posehip import inference
+    frames = synth.synth_frames(7, 5, 64, 96)
+    for tag in ("a", "b"):
+        os.makedirs(tmp_path / tag / "color")
+        for i, f in enumerate(frames):
+            Image.fromarray(np.ascontiguousarray(f[:, :, ::-1])).save(str(tmp_path / tag / "color" / f"{i:06d}.png"))
+    # model FILES in OpenPose's folder layout (written here: none exist offline), output convs loud enough
+    # that the random net's noise assembles into "people" the writers have something to write about
+    from posehip import caffe_io, graph
+    proto = caffe_io.body25_prototxt(368, 656)
+    mdir = tmp_path / "models" / "pose" / "body_25"
+    os.makedirs(mdir)
+    open(mdir / "pose_deploy.prototxt", "w").write(proto)
+    caffe_io.write_caffemodel(str(mdir / "pose_iter_584000.caffemodel"),
+                              graph.random_weights(caffe_io.parse_prototxt(proto), seed=3, out_gain=1.0))
+    ns, _ = ph_args.get_parser().parse_known_args(
+        ["--op-model-folder", str(tmp_path / "models") + "/", "--op-net-resolution=-1x64", "--op-image-width", "96",
+         "--op-image-height", "64", "--op-save-skel", "true", "--op-skel-thres", "0.0", "--op-display", "0",
+         "--posehip-batch", "4"])
+    pe = api_native.OpenPosePoseExtractor(ns)
+    ns.op_input_color_image = str(tmp_path / "a" / "color")
+    rt = inference.extract_2dskeletons_offline(ns, pe)
+    assert len(rt["PE"]) == 5 and all(v > 0 for v in rt["PE"])
+    # the reference's walk names every frame's file '<prefix>_skeleton.csv' with prefix '' (:395-404), so one
+    # file survives per folder: the last frame's
+    last_a = np.loadtxt(str(tmp_path / "a" / "skeleton" / "_skeleton.csv"), delimiter=",", ndmin=2)
+    ns.op_input_color_image = str(tmp_path / "b" / "color")
+    out = inference.extract_2dskeletons_offline_batched(ns, pe)
+    assert out["frames"] == 5 and out["failed"] == 0 and len(out["filtered_skel"]) == 5
+    last_b = np.loadtxt(str(tmp_path / "b" / "skeleton" / "_skeleton.csv"), delimiter=",", ndmin=2)
+    assert last_a.shape == last_b.shape and np.array_equal(last_a, last_b)
+    assert last_a.shape[0] >= 1 and last_a.shape[1] == 1 + 25 * 3       # score, then x,y,s per joint (:186-199)
+    assert all(fs != "0" for fs in out["filtered_skel"])
+
+    class Tracker:
+        name, tracks = "t", []
+
+        def __init__(self):
+            self.n = 0
+
+        def update(self, boxes, scores, keypoints, heatmaps, image_size):
+            assert boxes.shape == (len(scores), 4) and keypoints.shape[1:] == (25, 3) and image_size == (96, 64)
+            assert heatmaps.shape[:2] == (64, 96)
+            self.n += 1
+
+        def no_measurement_predict_and_update(self):
+            self.n += 1
+
+    tk = Tracker()
+    rt = inference.extract_2dskeletons_and_track_offline(ns, tracker=tk, pose_extractor=pe)
+    assert tk.n == 5 and len(rt["PE"]) == 5
+    pe.pyop.opWrapper.close()
