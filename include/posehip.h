@@ -126,8 +126,12 @@ float* ph_net_out_dev(ph_ctx* ctx);
 /* inject a net output (predict_from_hm, native/python/skeleton.py:469-481) */
 int ph_set_net_out(ph_ctx* ctx, const float* src, int on_device, int B, int C, int Hs, int Ws);
 /* bicubic-upsampled maps of one frame, channels [c0, c0+nc), to host f32
- * [nc][Ht][Wt]: datum.poseHeatMaps export (native/python/skeleton.py:64-76). */
-int ph_upsample_maps(ph_ctx* ctx, int frame, int c0, int nc, int Ht, int Wt, float* host_out);
+ * [nc][Ht][Wt]: datum.poseHeatMaps export (native/python/skeleton.py:64-76).
+ * n_heat: part + background channels of the net output (the rest are PAFs); scale_mode = OpenPose's
+ * --heatmaps_scale (params "heatmaps_scale", native/python/skeleton.py:531): 0 [-1,1], 1 [0,1],
+ * 2 integer-rounded [0,255], 3 as is. */
+int ph_upsample_maps(ph_ctx* ctx, int frame, int c0, int nc, int Ht, int Wt, int n_heat, int scale_mode,
+                     float* host_out);
 /* per-map global max and first raster location of it for all B*C maps of the
  * net output: cv2.minMaxLoc per heat map in postprocess_single
  * (opencv/skeleton.py:88-99).  vals f32 [B*C], locs i32 [B*C] (= y*Ws + x). */
@@ -166,6 +170,19 @@ int ph_decode_v2_results(ph_ctx* ctx, int32_t* n_people, float* keypoints, float
 int ph_pose_post(ph_ctx* ctx, int B, int max_people, int n_parts, const int32_t* torso_ids, int n_torso, float* bbox,
                  const uint16_t* depth, int depth_on_device, int Hd, int Wd, double fx, double fy, double cx, double cy,
                  double depth_scale, int patch_offset, double* kp3d);
+/* Tracker appearance feature of every person of the LAST ph_decode_v2(_dev), from the resident net output:
+ * the crop of the exported heat maps (channel windows `windows` = n_win x (c0, nc) of the net output,
+ * concatenated; bicubic to Ht x Wt; scale_mode as above) under the person's torso box, resampled to fx x fy
+ * by the reference's resize_tensor -- create_detections, tracking/utils_track.py:45-57, with
+ * openpose/native/python/utils.py:101-110 and tracking/track.py:180-183 (s_w = Wt/img_w, s_h = Ht/img_h).
+ * The upsampled maps are never materialised.  People of all frames are packed in frame order:
+ *   feat   f32 [n_rows][fy][fx][C]   (C = sum of the window widths; row 0 / column 0 zero as in the reference)
+ *   status i32 [n_rows]  1 ok, -1 crop with fewer than 2 rows/columns (the reference raises IndexError)
+ *   n_rows = people of all B frames; returns -3 (nothing copied) if it exceeds `capacity`.
+ * Synchronises the stream. */
+int ph_pose_features(ph_ctx* ctx, int B, int max_people, int n_parts, const int32_t* torso_ids, int n_torso,
+                     const int32_t* windows, int n_win, int n_heat, int scale_mode, int Ht, int Wt, int img_w, int img_h,
+                     int fx, int fy, int capacity, float* feat, int32_t* status, int32_t* n_rows);
 
 /* test/debug: per-limb connections of the last decode.  n_conn i32 [B][n_pairs],
  * conn_idx i32 [B][n_pairs][max_peaks][2] (upstream peak indices part*3*(max_peaks+1)

@@ -18,6 +18,10 @@ int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t str
 bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32);
 int ph_launch_torso_bbox(const float* kp, const int* n_people, int B, int maxp, int J, const int* ids, int n_ids,
                          float* out, hipStream_t stream);
+int ph_launch_pose_features(const float* net_out, int C, int hs, int ws, const float* bbox, const int* n_people, int B,
+                            int maxp, const int* windows, int n_win, int n_heat, int mode, int Ht, int Wt, int img_w,
+                            int img_h, int fx, int fy, int capacity, float* feat, int* status, int* total,
+                            hipStream_t stream);
 int ph_launch_lift3d(const float* kp, const int* n_people, int B, int maxp, int J, const uint16_t* depth, int Hd,
                      int Wd, double fx, double fy, double cx, double cy, double depth_scale, int po, double* out,
                      hipStream_t stream);
@@ -645,8 +649,12 @@ int ph_get_buffer(ph_ctx* c, int buf, uint16_t* host_out, int64_t n_elems) {
   return 0;
 }
 
-int ph_upsample_maps(ph_ctx* c, int frame, int c0, int nc, int Ht, int Wt, float* host_out) {
+int ph_upsample_maps(ph_ctx* c, int frame, int c0, int nc, int Ht, int Wt, int n_heat, int scale_mode, float* host_out) {
   PH_CHECK(hipSetDevice(c->device));
+  if (scale_mode < 0 || scale_mode > 3) {
+    ph_set_error("ph_upsample_maps: heatmaps_scale %d (0..3)", scale_mode);
+    return -1;
+  }
   if (!c->cur_out || frame < 0 || c0 < 0 || nc < 1 || c0 + nc > c->cur_c || Ht < 1 || Wt < 1 ||
       (size_t)(frame + 1) * c->cur_c * c->cur_h * c->cur_w > c->cur_elems) {
     ph_set_error("ph_upsample_maps: bad frame/channel window");
@@ -656,7 +664,7 @@ int ph_upsample_maps(ph_ctx* c, int frame, int c0, int nc, int Ht, int Wt, float
   const size_t n = (size_t)nc * Ht * Wt;
   PH_CHECK(hipMalloc(&tmp, n * sizeof(float)));
   const float* planes = c->cur_out + ((size_t)frame * c->cur_c + c0) * c->cur_h * c->cur_w;
-  int rc = ph_launch_upsample_maps(planes, c->cur_h, c->cur_w, Ht, Wt, nc, tmp, c->stream);
+  int rc = ph_launch_upsample_maps(planes, c->cur_h, c->cur_w, Ht, Wt, nc, n_heat - c0, scale_mode, tmp, c->stream);
   if (!rc && hipMemcpyAsync(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -1;
   if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
   (void)hipFree(tmp);
@@ -846,6 +854,74 @@ int ph_pose_post(ph_ctx* c, int B, int max_people, int n_parts, const int32_t* t
     PH_CHECK(hipMemcpyAsync(kp3d, base + off_3d, n_3d, hipMemcpyDeviceToHost, s));
   }
   PH_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int ph_pose_features(ph_ctx* c, int B, int max_people, int n_parts, const int32_t* torso_ids, int n_torso,
+                     const int32_t* windows, int n_win, int n_heat, int scale_mode, int Ht, int Wt, int img_w, int img_h,
+                     int fx, int fy, int capacity, float* feat, int32_t* status, int32_t* n_rows) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!c->v2.n_people || !c->cur_out || B < 1 || max_people < 1 || n_parts < 1 ||
+      (size_t)B * max_people * n_parts * 3 * sizeof(float) > c->v2sz.keypoints ||
+      (size_t)B * c->cur_c * c->cur_h * c->cur_w > c->cur_elems) {
+    ph_set_error("ph_pose_features: no V2 decode of %d x %d x %d keypoints / net output has run", B, max_people, n_parts);
+    return -1;
+  }
+  if (!torso_ids || n_torso < 1 || n_torso > 64 || !windows || n_win < 1 || n_win > 4 || !feat || !status || !n_rows ||
+      capacity < 1 || fx < 1 || fy < 1 || Ht < 1 || Wt < 1 || img_w < 1 || img_h < 1 || scale_mode < 0 || scale_mode > 3) {
+    ph_set_error("ph_pose_features: bad arguments");
+    return -1;
+  }
+  for (int k = 0; k < n_torso; k++)
+    if (torso_ids[k] < 0 || torso_ids[k] >= n_parts) {
+      ph_set_error("ph_pose_features: torso id %d out of range", torso_ids[k]);
+      return -1;
+    }
+  int nch = 0;
+  for (int k = 0; k < n_win; k++) {
+    if (windows[2 * k] < 0 || windows[2 * k + 1] < 1 || windows[2 * k] + windows[2 * k + 1] > c->cur_c) {
+      ph_set_error("ph_pose_features: channel window %d out of range", k);
+      return -1;
+    }
+    nch += windows[2 * k + 1];
+  }
+  const size_t row = (size_t)fy * fx * nch * sizeof(float);
+  const size_t n_bb = (size_t)B * max_people * 4 * sizeof(float);
+  const size_t n_st = (size_t)capacity * sizeof(int32_t);
+  const size_t off_bb = 512, off_st = off_bb + ((n_bb + 255) & ~(size_t)255), off_ft = off_st + ((n_st + 255) & ~(size_t)255);
+  const size_t need = off_ft + (size_t)capacity * row;
+  hipStream_t s = c->stream;
+  if (need > c->post_bytes) {
+    PH_CHECK(hipStreamSynchronize(s));
+    if (c->post) PH_CHECK(hipFree(c->post));
+    c->post = nullptr;
+    c->post_bytes = 0;
+    PH_CHECK(hipMalloc(&c->post, need));
+    c->post_bytes = need;
+  }
+  char* base = (char*)c->post;  // [0,256) torso ids, [256,260) row total
+  PH_CHECK(hipMemcpyAsync(base, torso_ids, n_torso * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  PH_CHECK(hipMemsetAsync(base + off_st, 0, n_st, s));
+  if (ph_launch_torso_bbox(c->v2.keypoints, c->v2.n_people, B, max_people, n_parts, (const int*)base, n_torso,
+                           (float*)(base + off_bb), s))
+    return -1;
+  if (ph_launch_pose_features(c->cur_out, c->cur_c, c->cur_h, c->cur_w, (const float*)(base + off_bb), c->v2.n_people, B,
+                              max_people, windows, n_win, n_heat, scale_mode, Ht, Wt, img_w, img_h, fx, fy, capacity,
+                              (float*)(base + off_ft), (int*)(base + off_st), (int*)(base + 256), s))
+    return -1;
+  int32_t total = 0;
+  PH_CHECK(hipMemcpyAsync(&total, base + 256, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  PH_CHECK(hipStreamSynchronize(s));
+  *n_rows = total;
+  if (total > capacity) {
+    ph_set_error("ph_pose_features: %d people, feature buffer holds %d", total, capacity);
+    return -3;
+  }
+  if (total > 0) {
+    PH_CHECK(hipMemcpyAsync(feat, base + off_ft, (size_t)total * row, hipMemcpyDeviceToHost, s));
+    PH_CHECK(hipMemcpyAsync(status, base + off_st, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PH_CHECK(hipStreamSynchronize(s));
+  }
   return 0;
 }
 

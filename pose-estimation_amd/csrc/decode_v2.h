@@ -37,6 +37,7 @@ struct PhV2Buffers {
 int ph_v2_workspace_sizes(const PhV2Dev& m, int B, int max_people, PhV2Sizes* s);
 int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int Wt, const PhV2Dev& m, int B,
                         float scale, int max_people, const PhV2Buffers& w, hipStream_t stream, hipEvent_t* ev);
-int ph_launch_upsample_maps(const float* planes, int hs, int ws, int Ht, int Wt, int nc, float* out,
+int ph_launch_upsample_maps(const float* planes, int hs, int ws, int Ht, int Wt, int nc, int n_heat_rel, int mode,
+                            float* out,
                             hipStream_t stream);
 int ph_launch_argmax_maps(const float* maps, int n_maps, int n, float* vals, int* locs, hipStream_t stream);

@@ -17,64 +17,7 @@
 #include "common.h"
 #include "decode_v2.h"
 
-// ---------------------------------------------------------------------------
-// bicubic pieces (upstream cuda.hu cubicInterpolate / bicubicInterpolate)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float cubic(float v0, float v1, float v2, float v3, float d) {
-  const float a = (((-0.5f * v0 + 1.5f * v1) - 1.5f * v2) + 0.5f * v3);
-  const float b = (((v0 - 2.5f * v1) + 2.0f * v2) - 0.5f * v3);
-  const float c = 0.5f * (v0 - v2);
-  return ((((a * d) * d) * d + (b * d) * d) - c * d) + v1;
-}
-
-struct Taps {
-  int i0, i1, i2, i3;
-  float d;
-};
-
-__device__ __forceinline__ Taps src_taps(int x, int n_target, int n_source) {
-  const float xs = (((float)x + 0.5f) * (float)n_source) / (float)n_target - 0.5f;
-  int i1 = (int)floorf(xs);
-  i1 = i1 < 0 ? 0 : (i1 > n_source - 1 ? n_source - 1 : i1);
-  Taps t;
-  t.i1 = i1;
-  t.i0 = i1 - 1 < 0 ? 0 : i1 - 1;
-  t.i2 = i1 + 1 > n_source - 1 ? n_source - 1 : i1 + 1;
-  t.i3 = t.i2 + 1 > n_source - 1 ? n_source - 1 : t.i2 + 1;
-  t.d = xs - (float)i1;
-  return t;
-}
-
-// packed taps kept in LDS tables (one fp32 division per output column/row per block
-// instead of one per pixel)
-struct __attribute__((aligned(4))) TapsP {
-  unsigned short i0, i1, i2, i3;
-  float d;
-};
-__device__ __forceinline__ TapsP pack_taps(const Taps& t) {
-  TapsP p;
-  p.i0 = (unsigned short)t.i0;
-  p.i1 = (unsigned short)t.i1;
-  p.i2 = (unsigned short)t.i2;
-  p.i3 = (unsigned short)t.i3;
-  p.d = t.d;
-  return p;
-}
-
-__device__ __forceinline__ float cubic_row(const float* r, const TapsP& tx) {
-  return cubic(r[tx.i0], r[tx.i1], r[tx.i2], r[tx.i3], tx.d);
-}
-__device__ __forceinline__ float bicubic_tp(const float* src, int ws, const TapsP& tx, const TapsP& ty) {
-  const float t0 = cubic_row(src + ty.i0 * ws, tx), t1 = cubic_row(src + ty.i1 * ws, tx);
-  const float t2 = cubic_row(src + ty.i2 * ws, tx), t3 = cubic_row(src + ty.i3 * ws, tx);
-  return cubic(t0, t1, t2, t3, ty.d);
-}
-
-// one pixel of the upsampled map from a source plane (LDS or global)
-__device__ __forceinline__ float bicubic_at(const float* src, int hs, int ws, int Ht, int Wt, int x, int y) {
-  const TapsP tx = pack_taps(src_taps(x, Wt, ws)), ty = pack_taps(src_taps(y, Ht, hs));
-  return bicubic_tp(src, ws, tx, ty);
-}
+#include "bicubic.h"
 
 // ---------------------------------------------------------------------------
 // kernel 1a: fused bicubic upsample + strict 3x3 NMS + ordered compaction.
@@ -664,23 +607,25 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
 // decode itself never needs them).  grid-stride over [nc][Ht][Wt] of one frame.
 // ---------------------------------------------------------------------------
 __global__ void upsample_maps_kernel(const float* __restrict__ planes, int hs, int ws, int Ht, int Wt, int nc,
-                                     float* __restrict__ out) {
+                                     int n_heat_rel, int mode, float* __restrict__ out) {
   const size_t total = (size_t)nc * Ht * Wt;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int x = i % Wt;
     const size_t t = i / Wt;
     const int y = t % Ht;
     const int c = t / Ht;
-    out[i] = bicubic_at(planes + (size_t)c * hs * ws, hs, ws, Ht, Wt, x, y);
+    // channels [0, n_heat_rel) of the window are part/background maps, the rest PAFs
+    out[i] = heatmap_scale_value(bicubic_at(planes + (size_t)c * hs * ws, hs, ws, Ht, Wt, x, y), c < n_heat_rel, mode);
   }
 }
 
-int ph_launch_upsample_maps(const float* planes, int hs, int ws, int Ht, int Wt, int nc, float* out,
-                            hipStream_t stream) {
+int ph_launch_upsample_maps(const float* planes, int hs, int ws, int Ht, int Wt, int nc, int n_heat_rel, int mode,
+                            float* out, hipStream_t stream) {
   const size_t total = (size_t)nc * Ht * Wt;
   int blocks = (int)((total + 255) / 256);
   blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
-  hipLaunchKernelGGL(upsample_maps_kernel, dim3(blocks), dim3(256), 0, stream, planes, hs, ws, Ht, Wt, nc, out);
+  hipLaunchKernelGGL(upsample_maps_kernel, dim3(blocks), dim3(256), 0, stream, planes, hs, ws, Ht, Wt, nc, n_heat_rel,
+                     mode, out);
   PH_CHECK(hipGetLastError());
   return 0;
 }

@@ -75,7 +75,9 @@ SYMBOLS = {
     "ph_net_out_dev": (_vp, [_vp]),
     "ph_set_net_out": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int]),
-    "ph_upsample_maps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ph_upsample_maps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ph_pose_features": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ph_argmax_maps": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "ph_get_buffer": (C.c_int, [_vp, C.c_int, _vp, C.c_int64]),
     "ph_decode_v2": (C.c_int, [_vp, C.POINTER(PhV2Model), C.c_int, C.c_int,

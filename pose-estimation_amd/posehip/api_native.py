@@ -84,6 +84,8 @@ class Wrapper:
         self._model = None
         self._started = False
         self.want_raw = False       # fill datum.poseRawHeatMaps (one D2H of the net output)
+        self._last = None           # geometry of the last emplaceAndPop (for track_features)
+        self._feat = None           # its per-person features, computed on first use
 
     def configure(self, params: dict) -> None:
         self.params = dict(params)
@@ -130,6 +132,42 @@ class Wrapper:
             self._engine.build(plan, cap)
             self._built = (net_w, net_h, cap)
 
+    def _heatmap_windows(self):
+        """Channel windows of the net output that datum.poseHeatMaps concatenates (parts, background, PAFs)."""
+        p, model = self.params, self._model
+        chans = []
+        if p.get("heatmaps_add_parts"):
+            chans.append((0, model.n_parts))
+        if p.get("heatmaps_add_bkg"):
+            chans.append((model.n_parts, 1))
+        if p.get("heatmaps_add_PAFs"):
+            chans.append((model.n_heat, 2 * model.n_pairs))
+        return chans
+
+    def track_features(self, frame: int, image_size=None, size=(25, 50)):
+        """Addition: the tracker's appearance feature of every person of frame `frame` of the last
+        emplaceAndPop -- what ``create_detections`` (tracking/utils_track.py:45-57) cuts out of ``pose_heatmaps``
+        and resamples with ``resize_tensor`` -- computed on the GPU from the resident net output without
+        materialising the upsampled maps.  -> (features f64 [M, y*x*C], status i32 [M])"""
+        last = self._last
+        if last is None:
+            raise RuntimeError("no frame has been processed")
+        chans = self._heatmap_windows()
+        if not chans:
+            raise ValueError("heat maps are not enabled (heatmaps_add_parts / _bkg / _PAFs)")
+        image_size = tuple(image_size) if image_size is not None else last["image_size"]
+        key = (image_size, tuple(size))
+        if self._feat is None or self._feat[0] != key:
+            feat, status = self._engine.pose_features(
+                last["B"], last["max_people"], self._model.n_parts, TORSO_IDS, chans, self._model.n_heat,
+                int(self.params.get("heatmaps_scale", 2)), last["net_h"], last["net_w"], image_size,
+                sum(last["counts"]), size)
+            self._feat = (key, feat, status)
+        _, feat, status = self._feat
+        lo = sum(last["counts"][:frame])
+        hi = lo + last["counts"][frame]
+        return feat[lo:hi].reshape(hi - lo, -1).astype(np.float64), status[lo:hi]
+
     def emplaceAndPop(self, datums: List[Datum]) -> bool:
         """Synchronous full pipeline on a list of datums (all frames must share
         one image size); results are written into each datum."""
@@ -165,21 +203,22 @@ class Wrapper:
         res, _ = eng.decode_v2(model, B, net_h, net_w, scale=scale,
                                max_people=int(p.get("number_people_max", 0)) or 128)
         want_hm = p.get("heatmaps_add_parts") or p.get("heatmaps_add_bkg") or p.get("heatmaps_add_PAFs")
+        chans = self._heatmap_windows()
+        hm_mode = int(p.get("heatmaps_scale", 2))     # OpenPose's flag default is 2; the reference passes 1
+        max_people = int(p.get("number_people_max", 0)) or 128
+        self._last = dict(B=B, net_h=net_h, net_w=net_w, max_people=max_people, image_size=(W0, H0),
+                          counts=[len(res[b][1]) for b in range(B)])
+        self._feat = None
         for b, d in enumerate(datums):
             kp, sc = res[b]
             d.poseKeypoints = kp if len(sc) else None
             d.poseScores = sc if len(sc) else None
             d.netInputSizes = [_Point(net_w, net_h)]
             d.poseRawHeatMaps = [raw[b:b + 1]] if raw is not None else []
+            d._ph_frame = b
             if want_hm:
-                chans = []
-                if p.get("heatmaps_add_parts"):
-                    chans.append((0, model.n_parts))
-                if p.get("heatmaps_add_bkg"):
-                    chans.append((model.n_parts, 1))
-                if p.get("heatmaps_add_PAFs"):
-                    chans.append((model.n_heat, 2 * model.n_pairs))
-                d.poseHeatMaps = np.concatenate([eng.upsample_maps(b, c0, nc, net_h, net_w) for c0, nc in chans])
+                d.poseHeatMaps = np.concatenate([eng.upsample_maps(b, c0, nc, net_h, net_w, model.n_heat, hm_mode)
+                                                 for c0, nc in chans])
             else:
                 d.poseHeatMaps = None
             img = np.zeros((H0, W0, 3), np.uint8) if p.get("disable_blending") else frames[b].copy()
@@ -521,6 +560,21 @@ class PyOpenPoseNative(PyOpenPoseNativeBase):
                 self._pose_scores = np.stack(scores_filtered, axis=0)
             self.filtered_skel = f"{len(keypoints_filtered)}/{len(scores)}"
         return
+
+    def pose_track_features(self, image_size: Optional[Tuple[int, int]] = None,
+                            size: Tuple[int, int] = (25, 50)) -> Optional[np.ndarray]:
+        """Addition: ``[M, size_y*size_x*C]`` float64, row m = the ``feature`` that
+        ``create_detections(keypoints, scores, pose_bounding_box, pose_heatmaps, [s_w, s_h])``
+        (tracking/utils_track.py:32-59, scales from tracking/track.py:180-181) builds for person m of the
+        current frame, computed on the GPU.  ``image_size`` = (width, height) as the tracker receives it
+        (default: the frame's own size).  Raises IndexError where the reference's ``resize_tensor`` does
+        (a crop with fewer than two rows or columns)."""
+        if self.pose_empty or self.datum.poseScores is None:
+            return None
+        feat, status = self.opWrapper.track_features(getattr(self.datum, "_ph_frame", 0), image_size, size)
+        if (status < 0).any():
+            raise IndexError("index 1 is out of bounds: a person's heat-map crop has fewer than 2 rows or columns")
+        return feat
 
 
 def read_heatmap_file(path: str) -> List[np.ndarray]:

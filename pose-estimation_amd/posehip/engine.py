@@ -110,10 +110,12 @@ class Engine:
                        "ph_set_net_out")
         self._injected = (B, Cc, Hs, Ws)
 
-    def upsample_maps(self, frame, c0, nc, Ht, Wt):
+    def upsample_maps(self, frame, c0, nc, Ht, Wt, n_heat=0, scale_mode=3):
+        """Bicubic-upsampled maps [nc,Ht,Wt] of channels [c0, c0+nc) of one frame; `scale_mode` = OpenPose's
+        --heatmaps_scale (3 = as is), channels below `n_heat` are part/background maps, the rest PAFs."""
         out = np.empty((nc, Ht, Wt), np.float32)
-        _ffi.check(self._lib.ph_upsample_maps(self._ctx, int(frame), int(c0), int(nc), int(Ht), int(Wt), _ptr(out)),
-                   "ph_upsample_maps")
+        _ffi.check(self._lib.ph_upsample_maps(self._ctx, int(frame), int(c0), int(nc), int(Ht), int(Wt), int(n_heat),
+                                              int(scale_mode), _ptr(out)), "ph_upsample_maps")
         return out
 
     def argmax_maps(self, B, C_, Ws):
@@ -211,6 +213,27 @@ class Engine:
                                           float(depth_scale), int(patch_offset),
                                           _ptr(kp3d) if kp3d is not None else None), "ph_pose_post")
         return bbox, kp3d
+
+    def pose_features(self, B, max_people, n_parts, torso_ids, windows, n_heat, scale_mode, Ht, Wt, image_size,
+                      n_rows, size=(25, 50)):
+        """Tracker appearance features of the people of the last decode_v2(_dev), straight from the resident net
+        output (create_detections' crop + resize_tensor, tracking/utils_track.py:45-57).
+        windows: [(c0, nc), ...] channel windows of the net output; image_size = (width, height) of the frames;
+        n_rows: people of all B frames (known from the decode); size = (x, y) of the resampled crop.
+        -> (feat f32 [n_rows, y, x, C], status i32 [n_rows]: 1 ok / -1 degenerate crop)"""
+        ids = np.ascontiguousarray(torso_ids, np.int32)
+        win = np.ascontiguousarray(windows, np.int32).reshape(-1, 2)
+        nch = int(win[:, 1].sum())
+        fx, fy = int(size[0]), int(size[1])
+        cap = max(int(n_rows), 1)
+        feat = np.zeros((cap, fy, fx, nch), np.float32)
+        status = np.zeros((cap,), np.int32)
+        total = C.c_int32(0)
+        _ffi.check(self._lib.ph_pose_features(self._ctx, int(B), int(max_people), int(n_parts), _ptr(ids), len(ids),
+                                              _ptr(win), len(win), int(n_heat), int(scale_mode), int(Ht), int(Wt),
+                                              int(image_size[0]), int(image_size[1]), fx, fy, cap, _ptr(feat),
+                                              _ptr(status), C.byref(total)), "ph_pose_features")
+        return feat[:total.value], status[:total.value]
 
     def decode_v2_connections(self, model, B):
         """Test/debug: per-limb connection lists of the last decode."""

@@ -310,3 +310,42 @@ def test_pipeline_callers_on_the_engine(tmp_path):
     rt = inference.extract_2dskeletons_and_track_offline(ns, tracker=tk, pose_extractor=pe)
     assert tk.n == 5 and len(rt["PE"]) == 5
     pe.pyop.opWrapper.close()
+
+
+def test_tracker_features_device_equals_host_path():
+    """create_detections on the exported pose_heatmaps (host, as the reference) and the on-device
+    feature give the same detections; --heatmaps_scale 1 as OpenPosePoseExtractor passes it."""
+    from posehip import utils_track
+    from posehip.tables import BODY_25
+    params = dict(model_folder="/nonexistent/", model_pose="BODY_25", net_resolution="-1x368", posehip_random_weights=0,
+                  heatmaps_add_parts=True, heatmaps_add_bkg=True, heatmaps_add_PAFs=True, heatmaps_scale=1)
+    pyop = api_native.PyOpenPoseNative(params, 0.0, 8, 2)
+    img = np.zeros((368, 656, 3), np.uint8)
+    pyop.predict_from_hm(img, [synth.synth_net_output(41, 4, BODY_25, 46, 82)[None]])
+    assert not pyop.pose_empty and len(pyop.pose_scores) >= 3
+    hm = pyop.pose_heatmaps
+    assert hm.shape == (368, 656, 78) and hm.min() >= 0.0 and hm.max() <= 1.0        # mode 1: everything in [0,1]
+    image_size = (656, 368)
+    host = utils_track.create_detections(pyop.pose_keypoints, pyop.pose_scores, pyop.pose_bounding_box, hm,
+                                         [hm.shape[1] / image_size[0], hm.shape[0] / image_size[1]])
+    dev = utils_track.create_detections_device(pyop, image_size)
+    assert len(host) == len(dev) == len(pyop.pose_scores)
+    for h, d in zip(host, dev):
+        assert h.feature.shape == d.feature.shape == (50 * 25 * 78,) and d.feature.dtype == np.float64
+        np.testing.assert_array_equal(h.feature, d.feature)
+        np.testing.assert_array_equal(h.tlwh, d.tlwh)
+        assert h.feature.any()
+    # second frame of a batch
+    d2 = [api_native.Datum(), api_native.Datum()]
+    for i, d in enumerate(d2):
+        d.cvInputData = img
+        d.customInputNetData = [synth.synth_net_output(50 + i, 2 + i, BODY_25, 46, 82)[None]]
+    pyop.opWrapper.emplaceAndPop(d2)
+    pyop.adopt(d2[1])
+    feats = pyop.pose_track_features()
+    hm1 = pyop.pose_heatmaps
+    want = utils_track.create_detections(pyop.pose_keypoints, pyop.pose_scores, pyop.pose_bounding_box, hm1, [1.0, 1.0])
+    assert len(want) == len(feats) > 0
+    for w, f in zip(want, feats):
+        np.testing.assert_array_equal(w.feature, f)
+    pyop.opWrapper.close()

@@ -120,3 +120,81 @@ def test_pose_post_matches_oracle_bit_exact(engine):
                 np.testing.assert_array_equal(kp3d[b, p].view(np.uint64), want.view(np.uint64))
     with pytest.raises(_ffi.PosehipError):
         engine.pose_post(B, 128, BODY_25.n_parts, [99], None)             # torso id out of range
+
+
+def test_exported_heatmaps_follow_heatmaps_scale(engine):
+    """datum.poseHeatMaps export: bicubic maps mapped by --heatmaps_scale, bit-exact vs oracle/features.py."""
+    from oracle import features
+    hs, ws = 12, 20
+    rng = np.random.default_rng(31)
+    net = rng.normal(0.3, 0.8, (2, BODY_25.n_channels, hs, ws)).astype(np.float32)   # values beyond [-1,1] too
+    engine.set_net_out(net)
+    for mode in (0, 1, 2, 3):
+        for c0, nc in ((0, 25), (25, 1), (26, 52), (20, 12)):
+            got = engine.upsample_maps(1, c0, nc, hs * 8, ws * 8, BODY_25.n_heat, mode)
+            want = features.export_heatmaps(net[1], [(c0, nc)], BODY_25.n_heat, mode, hs * 8, ws * 8)
+            np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32), err_msg=f"mode {mode} window {c0}")
+    with pytest.raises(_ffi.PosehipError):
+        engine.upsample_maps(0, 0, 25, hs * 8, ws * 8, BODY_25.n_heat, 4)
+
+
+def test_pose_features_match_oracle_bit_exact(engine):
+    """the tracker feature (create_detections' crop of the exported heat maps under the torso box +
+    resize_tensor to 25x50, tracking/utils_track.py:45-57) computed per person from the resident net output equals
+    the oracle's crop of the fully materialised maps, bit for bit -- all scale modes, channel selections, an image
+    size different from the net input size, frames without people, degenerate boxes."""
+    from oracle import features, post_v2
+    from posehip.tables import TORSO_IDS
+    B, hs, ws = 3, 46, 82
+    Ht, Wt = hs * 8, ws * 8
+    net = np.stack([synth.synth_net_output(700 + i, [3, 0, 5][i], BODY_25, hs, ws) for i in range(B)])
+    engine.set_net_out(net)
+    all_win = [(0, 25), (25, 1), (26, 52)]
+    for image_size, scale, mode, windows, size in (((656, 368), 1.0, 1, all_win, (25, 50)),
+                                                   ((1920, 1080), 1080 / 368, 2, [(0, 25)], (25, 50)),
+                                                   ((1920, 1080), 1080 / 368, 0, [(0, 25), (26, 52)], (7, 4)),
+                                                   ((656, 368), 1.0, 3, [(25, 1)], (25, 50))):
+        res, ex = engine.decode_v2(BODY_25, B, Ht, Wt, scale, 128)
+        counts = [len(res[b][1]) for b in range(B)]
+        assert counts[1] == 0 and counts[0] > 0 and counts[2] > 0
+        feat, status = engine.pose_features(B, 128, BODY_25.n_parts, TORSO_IDS, windows, BODY_25.n_heat, mode, Ht, Wt,
+                                            image_size, sum(counts), size)
+        nch = sum(nc for _, nc in windows)
+        assert feat.shape == (sum(counts), size[1], size[0], nch) and status.shape == (sum(counts),)
+        row = 0
+        for b in range(B):
+            if not counts[b]:
+                continue
+            hm = np.moveaxis(features.export_heatmaps(net[b], windows, BODY_25.n_heat, mode, Ht, Wt), 0, -1)
+            want = features.detection_features(post_v2.torso_bbox(res[b][0], TORSO_IDS), hm, image_size, size)
+            for w in want:
+                if isinstance(w, Exception):
+                    assert status[row] == -1 and not feat[row].any()
+                else:
+                    assert status[row] == 1
+                    assert w.dtype == np.float64
+                    np.testing.assert_array_equal(feat[row].reshape(-1).astype(np.float64), w)
+                    assert feat[row].any()
+                row += 1
+        assert row == sum(counts)
+    # a buffer too small for the people found is refused, not overrun
+    with pytest.raises(_ffi.PosehipError):
+        engine.pose_features(B, 128, BODY_25.n_parts, TORSO_IDS, all_win, BODY_25.n_heat, 1, Ht, Wt, (656, 368), 2)
+    with pytest.raises(_ffi.PosehipError):
+        engine.pose_features(B, 128, BODY_25.n_parts, TORSO_IDS, [(70, 20)], BODY_25.n_heat, 1, Ht, Wt, (656, 368), 8)
+
+
+def test_pose_features_degenerate_crop_flags_index_error(engine):
+    """A person whose torso box maps to a one-column crop: the reference's resize_tensor raises IndexError; the
+    kernel reports status -1 and zeros."""
+    from posehip.tables import TORSO_IDS
+    hs, ws = 46, 82
+    net = synth.synth_net_output(701, 2, BODY_25, hs, ws)[None]
+    engine.set_net_out(net)
+    res, _ = engine.decode_v2(BODY_25, 1, hs * 8, ws * 8, 1.0, 128)
+    n = len(res[0][1])
+    assert n > 0
+    # an image "size" so wide that every box collapses to <= 1 heat-map column
+    feat, status = engine.pose_features(1, 128, BODY_25.n_parts, TORSO_IDS, [(0, 25)], BODY_25.n_heat, 1, hs * 8, ws * 8,
+                                        (656 * 4000, 368), n)
+    assert (status == -1).all() and not feat.any()

@@ -174,3 +174,33 @@ def test_post_v2_known_answers():
     avg1 = np.mean([0, 10, 100, 110])
     assert out[1, 2] == avg1 * 1e-3
     assert np.isnan(out[2]).all()                                 # patch outside the image: nanmean of nothing
+
+
+def test_feature_oracle_pinned_by_the_reference_and_known_answers():
+    """oracle/features.py: resize_tensor equals the REFERENCE's own outputs (tests/golden/callers_ref.npz, made by
+    openpose/native/python/utils.py); heatmaps_scale known answers; crop rules of create_detections."""
+    import os
+    from oracle import features
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "callers_ref.npz"))
+    for i in range(5):
+        x, y = (int(v) for v in g[f"rt{i}_xy"])
+        assert np.array_equal(features.resize_tensor(g[f"rt{i}_in"], x, y), g[f"rt{i}_out"])
+    v = np.array([-1.5, -1.0, -0.25, 0.0, 0.25, 0.999, 1.0, 1.7], np.float32)
+    assert features.scale_values(v, True, 3) is not None and np.array_equal(features.scale_values(v, True, 3), v)
+    assert features.scale_values(v, True, 1).tolist() == [0, 0, 0, 0, 0.25, np.float32(0.999), 1, 1]
+    assert features.scale_values(v, True, 0).tolist() == [-1, -1, -1, -1, -0.5, np.float32(0.999) * 2 - 1, 1, 1]
+    assert features.scale_values(v, True, 2).tolist() == [0, 0, 0, 0, 64, 255, 255, 255]          # int(63.75 + .5)
+    assert features.scale_values(v, False, 1).tolist() == [0, 0, 0.375, 0.5, 0.625, np.float32(0.999) * np.float32(0.5) + np.float32(0.5), 1, 1]
+    assert features.scale_values(v, False, 2).tolist() == [0, 0, 96, 129, 161, 255, 255, 255]
+    assert features.scale_values(v, False, 0).tolist() == [-1, -1, -0.25, 0, 0.25, np.float32(0.999), 1, 1]
+    # crop + resample: a ramp map makes the sampled source indices visible
+    H, W = 40, 60
+    yy, xx = np.mgrid[0:H, 0:W]
+    hm = np.stack([yy, xx], axis=-1).astype(np.float32)
+    box = np.array([[10.0, 4.0, 31.5, 35.2]], np.float32)               # l, t, r, b in image pixels
+    f = features.detection_features(box, hm, (120, 80), (25, 50))[0].reshape(50, 25, 2)   # s_w = s_h = 0.5
+    assert not f[0].any() and not f[:, 0].any()
+    # crop rows 2:18 (h 16), columns 5:16 (w 11): out[i+1][j+1] = crop[1 + int(i/(50/15)), 1 + int(j/(25/10))]
+    assert f[1, 1].tolist() == [3.0, 6.0] and f[49, 24].tolist() == [2 + 1 + int(48 / (50 / 15)), 5 + 1 + int(23 / 2.5)]
+    wide = features.detection_features(np.array([[10.0, 4.0, 10.5, 35.0]], np.float32), hm, (120, 80))[0]
+    assert isinstance(wide, IndexError)
