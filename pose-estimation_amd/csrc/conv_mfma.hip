@@ -298,8 +298,18 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // TAPS = 9: 3x3 conv (halo patch, 9 K steps per 32-channel chunk).  TAPS = 1: 1x1 conv through the same
 // pipeline: the "patch" of a chunk is just the tile's 256 pixels, lives for one K step, and rotates through
 // three buffers (halo_mode 2: tiles are 256-long runs of the unpadded pixel index).
+//
+// LIN: branch-free steady state for the padded-linear form (halo_mode 0) at BN = 128.  Measured on conv4_2
+// (ablations, tools/conv_bench.py): the K step's non-MFMA part (barrier, LDS-DMA issue under uniform branches,
+// ~44 VALU of fragment addressing, 12 fragment reads and a full lgkmcnt(0) wait, a branch tree for the counted
+// vmcnt) took as long as its 32 MFMAs and overlapped with them hardly at all.  In LIN every wave issues the
+// same number of LDS-DMA instructions in every step (out-of-range pieces are clamped to a duplicate of the last
+// valid one, loads past the end of K re-fetch valid data into a free slot), so the vmcnt immediates, the weight
+// slot and the fragment offsets are compile-time constants and the loop body has no branches.
 template <int NREP, int MW, bool DBG, bool STEM = false, int TAPS = 9>  // MW waves along M x 2 along N
 __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConvParams p) {
+  constexpr bool LINC = !STEM && !DBG && TAPS == 9 && NREP == 4 && MW == 2;  // instantiation that has the LIN loop
+  const bool LIN = LINC && p.halo_mode == 0;
   constexpr int BN = 32 * NREP;
   constexpr int NW = 2 * MW;                   // waves per block
   constexpr int NT = 64 * NW;
@@ -392,7 +402,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   unsigned w_src[NBW];
 #pragma unroll
   for (int i = 0; i < NBW; i++) {
-    int n = n0 + (wave + i * NW) * 16 + (lane >> 2);
+    int piece = wave + i * NW;
+    if (LIN) piece = piece < NBI ? piece : NBI - 1;  // duplicate of the last piece instead of no instruction
+    int n = n0 + piece * 16 + (lane >> 2);
     n = n < p.cout_pad ? n : p.cout_pad - 1;
     w_src[i] = ((unsigned)n * (unsigned)p.Kpad + (unsigned)(lchunk * 8)) * 2u;  // BYTE offset
   }
@@ -403,18 +415,27 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   const int nchunks = p.cin_read >> 5;
   const int ns = nchunks * TAPS;
 
-  auto load_b = [&](int t, int cc, int slot) {  // weight slice of (tap t, chunk cc) -> slice slot `slot`
+  auto load_b = [&](int t, int cc, int slot, bool lin = false) {  // weight slice of (tap t, chunk cc) -> slice slot `slot`
     const unsigned k0 = (unsigned)(t * p.cin_read + cc * 32) * 2u;
     const char* wbase = (const char*)p.wt;  // uniform base + 32-bit lane offset: saddr addressing, no 64-bit VGPR pairs
-    char* sb = bring + slot * B_STAGE + wave * 1024;
+    char* sb = bring + slot * B_STAGE;
 #pragma unroll
-    for (int i = 0; i < NBW; i++)
-      if (wave + i * NW < NBI)
-        __builtin_amdgcn_global_load_lds((glb_void*)(wbase + (w_src[i] + k0)), (lds_void*)(sb + i * NW * 1024), 16, 0, 0);
+    for (int i = 0; i < NBW; i++) {
+      int piece = wave + i * NW;
+      if (LIN) piece = piece < NBI ? piece : NBI - 1;
+      if (lin || piece < NBI)
+        __builtin_amdgcn_global_load_lds((glb_void*)(wbase + (w_src[i] + k0)), (lds_void*)(sb + piece * 1024), 16, 0, 0);
+    }
   };
-  auto load_a = [&](int u, int cc, int buf) -> int {  // piece u of the patch of chunk cc
-    if (u * NW + wave >= p.NI) return 0;
-    char* sa = lds + buf * patch_bytes + (u * NW + wave) * 1024;
+  auto load_a = [&](int u, int cc, int buf, bool lin = false) -> int {  // piece u of the patch of chunk cc
+    int piece = u * NW + wave;
+    if (lin) {
+      piece = piece < p.NI ? piece : p.NI - 1;  // duplicate of the last piece (a_src is clamped the same way)
+    } else if (piece >= p.NI) {
+      if (!LIN) return 0;
+      piece = p.NI - 1;
+    }
+    char* sa = lds + buf * patch_bytes + piece * 1024;
     __builtin_amdgcn_global_load_lds((glb_void*)((const char*)p.in + (a_src[u] + (unsigned)(cc * 64))), (lds_void*)sa, 16, 0,
                                      0);
     return 1;
@@ -561,9 +582,91 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       }
     }
   }
+  if (LINC && LIN) {
+    // prologue issued, in this order: patch of chunk 0 (NPC per wave), weight slice 0 (NBW), weight slice 1 (NBW)
+    const char* const bb0 = bring + b_rd;
+#ifdef PH_LIN_STAMP
+    long long st[6] = {0, 0, 0, 0, 0, 0};
+    const long long m0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll 1
+    for (int cc = 0; cc < nchunks; cc++) {
+      const char* patch = lds + (cc & 1) * patch_bytes;
+      const int nbuf = (cc + 1) & 1;
+      const int cn = cc + 1 < nchunks ? cc + 1 : cc;  // past the end: re-fetch this chunk into the free buffer
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        // everything issued before the previous step has landed (previous step: NBW weight + 1 patch piece,
+        // none of the latter in tap 8)
+#ifdef PH_LIN_STAMP
+        long long cm = __builtin_readcyclecounter();
+#endif
+        if (t == 0)
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#ifdef PH_LIN_STAMP
+        long long c0 = __builtin_readcyclecounter();
+        st[5] += c0 - cm;
+#endif
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef PH_LIN_STAMP
+        long long c1 = __builtin_readcyclecounter();
+#endif
+        const char* bb = bb0 + (t % 3) * B_STAGE;
+        int pv = pjl;
+        asm volatile("" : "+v"(pv));  // (keeps the 9 tap offsets out of registers the accumulators need)
+        const int pj0 = pv + (t / 3) * p.SKH + (t % 3);
+        const char* ap = patch + pj0 * 64 + ((fq * 16) ^ ((pj0 & 4) << 3));
+#pragma unroll
+        for (int j = 0; j < NREP; j++) bfr[j] = *(const bf16x8*)(bb + j * 1024);
+#pragma unroll
+        for (int i = 0; i < IB; i++) af[i] = *(const bf16x8*)(ap + i * 1024);  // row block i: 16 pixels further on
+#ifdef PH_LIN_STAMP
+        long long c2 = __builtin_readcyclecounter();
+#endif
+        // weight slice of step s+2 -> slot (t+2)%3 (free since the barrier); piece t of the next chunk's patch
+        {
+          int t2 = t + 2, c2 = cc;
+          if (t2 >= 9) {
+            t2 -= 9;
+            c2 = cn;
+          }
+          load_b(t2, c2, (t + 2) % 3, true);
+          if (t < NPC) load_a(t, cn, nbuf, true);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef PH_LIN_STAMP
+        long long c3 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        long long c4 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int i = 0; i < IB; i++)
+#pragma unroll
+          for (int j = 0; j < NREP; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef PH_LIN_STAMP
+        long long c5 = __builtin_readcyclecounter();
+        st[0] += c1 - c0; st[1] += c2 - c1; st[2] += c3 - c2; st[3] += c4 - c3; st[4] += c5 - c4;
+#endif  // (or the MFMAs sink below the next barrier and the fragments double up)
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetches past the end of K
+#ifdef PH_LIN_STAMP
+    if (lane == 0 && wave == 1) {
+      for (int k = 0; k < 6; k++) atomicAdd(&ph_conv_dbg[k], (unsigned long long)st[k]);
+      atomicAdd(&ph_conv_dbg[6], (unsigned long long)(__builtin_amdgcn_s_memtime() - m0_));
+      atomicAdd(&ph_conv_dbg[7], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r0_));
+    }
+#endif
+  }
   int bslot = 0;
   int pbuf = 0;  // patch buffer of chunk cc
-  for (int cc = 0; !STEM && cc < nchunks; cc++) {
+  for (int cc = 0; !STEM && !(LINC && LIN) && cc < nchunks; cc++) {
     const char* patch = lds + pbuf * patch_bytes;
 #pragma unroll
     for (int t = 0; t < TAPS; t++) {
