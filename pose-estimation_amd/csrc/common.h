@@ -51,6 +51,7 @@ struct PhConvParams {
   int SKH, SI;           // patch pixel of (row block i, px, kh, kw) = kh*SKH + i*SI + kw + px
   int PR, PCLIP, NI;     // patch pixel j <-> input pixel Qbase + j + min(j/PR, PCLIP)*(Wp-PR); NI 16-pixel pieces
   unsigned magic_pr;
+  int lin;    // halo_mode 0 at BN = 128: branch-free K loop (POSEHIP_NO_LIN=1 turns it off for A/B runs)
   int debug;  // timing experiments only (POSEHIP_CONV_DEBUG): 1 skip A loads, 2 skip B loads, 4 skip MFMA
 };
 

@@ -309,7 +309,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 template <int NREP, int MW, bool DBG, bool STEM = false, int TAPS = 9>  // MW waves along M x 2 along N
 __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConvParams p) {
   constexpr bool LINC = !STEM && !DBG && TAPS == 9 && NREP == 4 && MW == 2;  // instantiation that has the LIN loop
-  const bool LIN = LINC && p.halo_mode == 0;
+  const bool LIN = LINC && p.lin;
   constexpr int BN = 32 * NREP;
   constexpr int NW = 2 * MW;                   // waves per block
   constexpr int NT = 64 * NW;
@@ -585,6 +585,8 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   if (LINC && LIN) {
     // prologue issued, in this order: patch of chunk 0 (NPC per wave), weight slice 0 (NBW), weight slice 1 (NBW)
     const char* const bb0 = bring + b_rd;
+    const int astep = SI * 64;  // row block i of a tap sits SI pixels further on (SI = 16 or 24: the swizzle bit, bit 2
+                                // of the pixel index, is the same for every i)
 #ifdef PH_LIN_STAMP
     long long st[6] = {0, 0, 0, 0, 0, 0};
     const long long m0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #pragma unroll
         for (int j = 0; j < NREP; j++) bfr[j] = *(const bf16x8*)(bb + j * 1024);
 #pragma unroll
-        for (int i = 0; i < IB; i++) af[i] = *(const bf16x8*)(ap + i * 1024);  // row block i: 16 pixels further on
+        for (int i = 0; i < IB; i++) af[i] = *(const bf16x8*)(ap + i * astep);
 #ifdef PH_LIN_STAMP
         long long c2 = __builtin_readcyclecounter();
 #endif
@@ -904,6 +906,11 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   }
 }
 
+static bool no_lin_env() {  // POSEHIP_NO_LIN=1: A/B switch, the generic K loop everywhere
+  static const char* e = getenv("POSEHIP_NO_LIN");
+  return e && e[0] == '1';
+}
+
 // Geometry of the halo kernel for one conv; returns false if the op does not fit it.
 bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
   if (kh == 1 && p.KW == 1) {  // 1x1: halo_mode 2, TAPS = 1 instantiation
@@ -912,6 +919,7 @@ bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
         (unsigned long long)p.cout_pad * p.Kpad * 2ull >= 0xffffffffull)
       return false;
     p.halo_mode = 2;
+    p.lin = 0;
     p.NI = 16;
     p.SKH = 0;
     p.SI = 16;
@@ -945,14 +953,19 @@ bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
     p.halo_mode = 1;
     p.tiles_x = (p.W + 15) / 16;
     p.tiles_y = (p.H + 15) / 16;
-    p.SKH = 18;
-    p.SI = 18;
-    p.PR = 18;
+    // 18 x 18 patch.  Outside the stem kernel its rows are kept 24 pixels apart (columns 18..23 are loaded and
+    // never read): a row-block stride that is a multiple of 8 pixels is what the branch-free K loop needs, and
+    // 27 pieces fit the same LDS budget as the padded-linear form.  The stem kernel builds a dense 18 x 18 patch.
+    const int pr = (p.stem || no_lin_env()) ? 18 : 24;
+    p.SKH = pr;
+    p.SI = pr;
+    p.PR = pr;
     p.PCLIP = 17;
-    p.NI = (18 * 18 + 15) / 16;
+    p.NI = (18 * pr + 15) / 16;
     p.n_mtiles = p.B * p.tiles_x * p.tiles_y;
   }
   p.magic_pr = ph_magic(p.PR);
+  p.lin = !no_lin_env() && !p.stem;
   return true;
 }
 
