@@ -52,6 +52,7 @@ struct PhConvParams {
   int PR, PCLIP, NI;     // patch pixel j <-> input pixel Qbase + j + min(j/PR, PCLIP)*(Wp-PR); NI 16-pixel pieces
   unsigned magic_pr;
   int lin;    // halo_mode 0 at BN = 128: branch-free K loop (POSEHIP_NO_LIN=1 turns it off for A/B runs)
+  int debug_epi;  // -DPH_LIN_STAMP builds: stamp the epilogue instead of the K loop (POSEHIP_STAMP_EPI=1)
   int debug;  // timing experiments only (POSEHIP_CONV_DEBUG): 1 skip A loads, 2 skip B loads, 4 skip MFMA
 };
 

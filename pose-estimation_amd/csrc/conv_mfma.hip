@@ -337,6 +337,10 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   const bool dbg_t = DBG && (p.debug & 8) != 0;
   long long t0 = 0, t1 = 0, t2 = 0, tw = 0;
   if (dbg_t) t0 = clock64();
+#ifdef PH_LIN_STAMP
+  const long long s0_ = __builtin_readcyclecounter();
+  long long sst_[4] = {0, 0, 0, 0};
+#endif
 
   const unsigned nblk = gridDim.x;
   const unsigned bid = blockIdx.x;
@@ -504,8 +508,15 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       t = t < 8 ? t : 8;  // taps 9..11 carry zero weights: read any finite pixel
       toff[ks] = ((t / 3) * 20 + (t % 3)) * 16;
     }
+#ifdef PH_LIN_STAMP
+    const long long sa_ = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef PH_LIN_STAMP
+    const long long sb_ = __builtin_readcyclecounter();
+    sst_[0] = sb_ - sa_;
+#endif
     prev_cnt = 0;  // everything issued so far has landed
     for (int rb = wave; rb < 21; rb += NW) {
       const int j = rb * 16 + lf;
@@ -535,6 +546,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       }
     }
     // (the first K step's barrier makes the patch visible to every wave)
+#ifdef PH_LIN_STAMP
+    sst_[1] = __builtin_readcyclecounter() - sb_;
+#endif
   }
   if (dbg_t) t1 = clock64();
 
@@ -555,9 +569,20 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #pragma unroll 1
     for (int s = 0; s < 6; s++) {
       const int cc = s / 3, kh = s - cc * 3;
+#ifdef PH_LIN_STAMP
+      const long long sc_ = __builtin_readcyclecounter();
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PH_LIN_STAMP
+      const long long sd_ = __builtin_readcyclecounter();
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef PH_LIN_STAMP
+      const long long se_ = __builtin_readcyclecounter();
+      sst_[2] += sd_ - sc_;
+      sst_[3] += se_ - sd_;
+#endif
       if (s + 1 < 6) {
         const int c1 = (s + 1) / 3, k1 = (s + 1) - c1 * 3;
 #pragma unroll
@@ -621,6 +646,12 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         asm volatile("" : "+v"(pv));  // (keeps the 9 tap offsets out of registers the accumulators need)
         const int pj0 = pv + (t / 3) * p.SKH + (t % 3);
         const char* ap = patch + pj0 * 64 + ((fq * 16) ^ ((pj0 & 4) << 3));
+        // weight slice of step s+2 -> slot (t+2)%3 (free since the barrier); piece t of the next chunk's patch
+        int t2 = t + 2, c2n = cc;
+        if (t2 >= 9) {
+          t2 -= 9;
+          c2n = cn;
+        }
 #pragma unroll
         for (int j = 0; j < NREP; j++) bfr[j] = *(const bf16x8*)(bb + j * 1024);
 #pragma unroll
@@ -628,16 +659,8 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #ifdef PH_LIN_STAMP
         long long c2 = __builtin_readcyclecounter();
 #endif
-        // weight slice of step s+2 -> slot (t+2)%3 (free since the barrier); piece t of the next chunk's patch
-        {
-          int t2 = t + 2, c2 = cc;
-          if (t2 >= 9) {
-            t2 -= 9;
-            c2 = cn;
-          }
-          load_b(t2, c2, (t + 2) % 3, true);
-          if (t < NPC) load_a(t, cn, nbuf, true);
-        }
+        load_b(t2, c2n, (t + 2) % 3, true);
+        if (t < NPC) load_a(t, cn, nbuf, true);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef PH_LIN_STAMP
         long long c3 = __builtin_readcyclecounter();
@@ -650,16 +673,16 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #pragma unroll
           for (int j = 0; j < NREP; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);  // (or the MFMAs sink below the next barrier and the fragments double up)
 #ifdef PH_LIN_STAMP
         long long c5 = __builtin_readcyclecounter();
         st[0] += c1 - c0; st[1] += c2 - c1; st[2] += c3 - c2; st[3] += c4 - c3; st[4] += c5 - c4;
-#endif  // (or the MFMAs sink below the next barrier and the fragments double up)
+#endif
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetches past the end of K
 #ifdef PH_LIN_STAMP
-    if (lane == 0 && wave == 1) {
+    if (lane == 0 && wave == 1 && !p.debug_epi) {
       for (int k = 0; k < 6; k++) atomicAdd(&ph_conv_dbg[k], (unsigned long long)st[k]);
       atomicAdd(&ph_conv_dbg[6], (unsigned long long)(__builtin_amdgcn_s_memtime() - m0_));
       atomicAdd(&ph_conv_dbg[7], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r0_));
@@ -773,6 +796,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
   }
   if (dbg_t) t2 = clock64();
+#ifdef PH_LIN_STAMP
+  const long long sk_ = __builtin_readcyclecounter();
+#endif
 
   // ---- epilogue --------------------------------------------------------------
   // acc[i][j][e]: pixel row (wm*IB*16 + i*16 + fr), channel (wn*BN/2 + j*16 + fq*4 + e)
@@ -791,6 +817,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         acc[i][j][e] = v;
       }
   }
+#ifdef PH_LIN_STAMP
+  const long long e1_ = __builtin_readcyclecounter();
+#endif
   __syncthreads();  // all fragment reads done, no LDS-DMA in flight (the last step waited for vmcnt(0))
   // per output row: {batch index or -1, y << 16 | x} (interior coordinates)
   int2* s_row = (int2*)(lds + HALO_BM * CROWB);  // behind the staged output tile (which may cover every other region)
@@ -834,6 +863,10 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
           if (cbase + j * 16 + e < nvalid) o[(size_t)(j * 16 + e) * hw] = acc[i][j][e];
     }
   }
+#ifdef PH_LIN_STAMP
+  const long long e2_ = __builtin_readcyclecounter();
+  long long e3_ = e2_;
+#endif
   if (p.n_dst > 0) {
     // the whole 256 x BN tile goes through LDS at once (bias/slope and the K-loop buffers are dead by now)
 #pragma unroll
@@ -846,25 +879,30 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         *(bf16x4*)(lds + (wm * IB * 16 + i * 16 + fr) * CROWB + (cbase + j * 16) * 2) = o;
       }
     __syncthreads();
+#ifdef PH_LIN_STAMP
+    e3_ = __builtin_readcyclecounter();
+#endif
     if (p.pool) {
       // 2x2/2 max pool of the 16x16 tile -> 8 x 8 pooled pixels
-      for (int v = tid; v < 64 * VPR; v += NT) {
-        const int prow = v / VPR;
-        const int cv = (v - prow * VPR) * 8;
-        const int r0 = (prow >> 3) * 32 + (prow & 7) * 2;
-        const int2 ri = s_row[r0];
-        if (ri.x < 0 || cv >= nvalid) continue;
-        const int y = ri.y >> 17, x = (ri.y & 0xffff) >> 1;
-        const char* sp = lds + r0 * CROWB + cv * 2;
-        const bf16x8 v00 = *(const bf16x8*)sp, v01 = *(const bf16x8*)(sp + CROWB);
-        const bf16x8 v10 = *(const bf16x8*)(sp + 16 * CROWB), v11 = *(const bf16x8*)(sp + 17 * CROWB);
-        bf16x8 mx;
+      // (destination loop outside: its descriptor is read once, not once per row)
+      for (int d = 0; d < p.n_dst; d++) {
+        const PhDst ds = p.dst[d];
+        bf16* const dbase = ds.base + (size_t)ds.org + n0;
+        for (int v = tid; v < 64 * VPR; v += NT) {
+          const int prow = v / VPR;
+          const int cv = (v - prow * VPR) * 8;
+          const int r0 = (prow >> 3) * 32 + (prow & 7) * 2;
+          const int2 ri = s_row[r0];
+          if (ri.x < 0 || cv >= nvalid) continue;
+          const int y = ri.y >> 17, x = (ri.y & 0xffff) >> 1;
+          const char* sp = lds + r0 * CROWB + cv * 2;
+          const bf16x8 v00 = *(const bf16x8*)sp, v01 = *(const bf16x8*)(sp + CROWB);
+          const bf16x8 v10 = *(const bf16x8*)(sp + 16 * CROWB), v11 = *(const bf16x8*)(sp + 17 * CROWB);
+          bf16x8 mx;
 #pragma unroll
-        for (int e = 0; e < 8; e++)
-          mx[e] = (bf16)fmaxf(fmaxf((float)v00[e], (float)v01[e]), fmaxf((float)v10[e], (float)v11[e]));
-        for (int d = 0; d < p.n_dst; d++) {
-          const PhDst& ds = p.dst[d];
-          bf16* o = ds.base + (size_t)ds.org + ((size_t)(ri.x * ds.Hp + y) * ds.Wp + x) * ds.Cs + n0 + cv;
+          for (int e = 0; e < 8; e++)
+            mx[e] = (bf16)fmaxf(fmaxf((float)v00[e], (float)v01[e]), fmaxf((float)v10[e], (float)v11[e]));
+          bf16* o = dbase + ((size_t)(ri.x * ds.Hp + y) * ds.Wp + x) * ds.Cs + cv;
           if (cv + 8 <= nvalid) {
             *(bf16x8*)o = mx;
           } else {
@@ -873,17 +911,19 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         }
       }
     } else {
-      for (int v = tid; v < HALO_BM * VPR; v += NT) {
-        const int row = v / VPR;
-        const int cv = (v - row * VPR) * 8;
-        const int2 ri = s_row[row];
-        if (ri.x < 0 || cv >= nvalid) continue;
-        const int y = ri.y >> 16, x = ri.y & 0xffff;
-        const char* sp = lds + row * CROWB + cv * 2;
-        const u32x4 val = *(const u32x4*)sp;
-        for (int d = 0; d < p.n_dst; d++) {
-          const PhDst& ds = p.dst[d];
-          bf16* o = ds.base + (size_t)ds.org + ((size_t)(ri.x * ds.Hp + y) * ds.Wp + x) * ds.Cs + n0 + cv;
+      for (int d = 0; d < p.n_dst; d++) {
+        const PhDst ds = p.dst[d];
+        bf16* const dbase = ds.base + (size_t)ds.org + n0;
+#pragma unroll 4
+        for (int v = tid; v < HALO_BM * VPR; v += NT) {
+          const int row = v / VPR;
+          const int cv = (v - row * VPR) * 8;
+          const int2 ri = s_row[row];
+          if (ri.x < 0 || cv >= nvalid) continue;
+          const int y = ri.y >> 16, x = ri.y & 0xffff;
+          const char* sp = lds + row * CROWB + cv * 2;
+          const u32x4 val = *(const u32x4*)sp;
+          bf16* o = dbase + ((size_t)(ri.x * ds.Hp + y) * ds.Wp + x) * ds.Cs + cv;
           if (cv + 8 <= nvalid) {
             *(u32x4*)o = val;
           } else {
@@ -893,6 +933,25 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       }
     }
   }
+#ifdef PH_LIN_STAMP
+  if (LINC && LIN && lane == 0 && wave == 1) {  // epilogue parts of the LIN instantiation: slots 0..3 of a second read-out
+    const long long e4_ = __builtin_readcyclecounter();
+    if (p.debug_epi) {
+      atomicAdd(&ph_conv_dbg[0], (unsigned long long)(e1_ - sk_));   // bias + activation
+      atomicAdd(&ph_conv_dbg[1], (unsigned long long)(e2_ - e1_));   // barrier + row table (+ fp32 output)
+      atomicAdd(&ph_conv_dbg[2], (unsigned long long)(e3_ - e2_));   // staging + barrier
+      atomicAdd(&ph_conv_dbg[3], (unsigned long long)(e4_ - e3_));   // store loop
+      atomicAdd(&ph_conv_dbg[4], 1ull);
+    }
+  }
+  if (STEM && lane == 0 && wave == 1) {
+    const long long se2_ = __builtin_readcyclecounter();
+    for (int k = 0; k < 4; k++) atomicAdd(&ph_conv_dbg[k], (unsigned long long)sst_[k]);
+    atomicAdd(&ph_conv_dbg[7], 1ull);
+    atomicAdd(&ph_conv_dbg[4], (unsigned long long)(sk_ - s0_));   // start .. end of K loop
+    atomicAdd(&ph_conv_dbg[5], (unsigned long long)(se2_ - sk_));  // epilogue
+  }
+#endif
   if (dbg_t) {
     __syncthreads();
     if (tid == 0) {

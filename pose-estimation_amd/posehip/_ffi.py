@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libposehip.so")
+# POSEHIP_LIB: another build of the same library (A/B timing of kernel variants); there is no other fallback
+LIB_PATH = os.environ.get("POSEHIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libposehip.so")
 
 PH_MAX_DST = 8
 PH_OP_CONV, PH_OP_POOL = 0, 1

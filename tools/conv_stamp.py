@@ -29,3 +29,6 @@ ms = eng.forward_timed(B); eng.sync(); L.ph_debug_conv_cycles(cyc, 0)
 n = 2016 * 144
 names = ["barrier wait", "addr+reads issue", "dma issue", "lgkm wait", "mfma issue", "vmcnt wait"]
 print("kernel ms", ms[1], " per step (wave 1 of every block):", {names[i]: round(cyc[i] / n, 1) for i in range(6)}, " loop cycles/block", cyc[6] // 2016, " in-kernel clock GHz", round(cyc[6] / max(1, cyc[7]) * 0.1, 3))
+if os.environ.get("POSEHIP_STAMP_EPI"):
+    nb = max(1, cyc[4])
+    print("epilogue per block:", {k: round(cyc[i] / nb) for i, k in enumerate(["bias+act", "barrier+row table", "staging+barrier", "store loop"])}, "blocks", nb)
