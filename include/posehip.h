@@ -184,6 +184,28 @@ int ph_pose_features(ph_ctx* ctx, int B, int max_people, int n_parts, const int3
                      const int32_t* windows, int n_win, int n_heat, int scale_mode, int Ht, int Wt, int img_w, int img_h,
                      int fx, int fy, int capacity, float* feat, int32_t* status, int32_t* n_rows);
 
+/* ---- MoveNet steps around the (remote, TF-Hub) model: SURVEY 8f-4, BASELINE configs[3] -------------------------
+ * on_device = 1: every pointer is device memory (no allocation, no copy); 0: host memory.  All synchronise.
+ *
+ * tf.image.crop_and_resize (bilinear, extrapolation 0) of one box per frame + cast to int32:
+ * crop_and_resize / run_inference, movenet/utils/image_sequence_crop.py:153-171.
+ *   frames u8 [B][H][W][3]; crop f64 [B][6] = y_min, x_min, y_max, x_max, height, width (normalised, the
+ *   reference's crop_region dict); out i32 [B][size][size][3] */
+int ph_movenet_crop_resize(ph_ctx* ctx, const uint8_t* frames, int B, int H, int W, const double* crop, int size,
+                           int32_t* out, int on_device);
+/* per stream: model output (y, x, score) from crop to image coordinates, in place (image_sequence_crop.py:178-186),
+ * then the next frame's crop region, determine_crop_region :94-150 (init_crop_region :15-40, torso_visible :43-56,
+ * determine_torso_and_body_range :59-91).  keypoints f32 [B][17][3]; crop_in / crop_out f64 [B][6]. */
+int ph_movenet_update(ph_ctx* ctx, float* keypoints, const double* crop_in, int B, int image_height, int image_width,
+                      double* crop_out, int on_device);
+/* MultiPose head decode (BASELINE configs[3]).  No counterpart in the reference tree (it only calls SinglePose
+ * graphs, whose decode is inside the TF-Hub model): the algorithm is specified in oracle/movenet.py
+ * (multipose_decode), parity unpinned.  Heads f32 on a G x G grid: center [B][G][G], kpt_heat [B][G][G][17],
+ * kpt_regr / kpt_offs [B][G][G][34], box_size [B][G][G][2]; out f32 [B][max_people][56]. */
+int ph_movenet_multipose_decode(ph_ctx* ctx, const float* center, const float* kpt_heat, const float* kpt_regr,
+                                const float* kpt_offs, const float* box_size, int B, int G, int max_people,
+                                float min_center, float* out, int on_device);
+
 /* test/debug: per-limb connections of the last decode.  n_conn i32 [B][n_pairs],
  * conn_idx i32 [B][n_pairs][max_peaks][2] (upstream peak indices part*3*(max_peaks+1)
  * + i*3 + 2), conn_score f32 [B][n_pairs][max_peaks]; any pointer may be NULL. */

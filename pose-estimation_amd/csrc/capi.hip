@@ -22,6 +22,13 @@ int ph_launch_pose_features(const float* net_out, int C, int hs, int ws, const f
                             int maxp, const int* windows, int n_win, int n_heat, int mode, int Ht, int Wt, int img_w,
                             int img_h, int fx, int fy, int capacity, float* feat, int* status, int* total,
                             hipStream_t stream);
+int ph_launch_movenet_crop_resize(const uint8_t* frames, int B, int H, int W, const double* crop, int S, int32_t* out,
+                                  hipStream_t stream);
+int ph_launch_movenet_update(float* kp, const double* crop_in, int B, int ih, int iw, double* crop_out,
+                             hipStream_t stream);
+int ph_launch_movenet_multipose(const float* center, const float* heat, const float* regr, const float* offs,
+                                const float* boxs, int B, int G, int maxp, float min_center, int* c_idx,
+                                float* c_score, float* out, hipStream_t stream);
 int ph_launch_lift3d(const float* kp, const int* n_people, int B, int maxp, int J, const uint16_t* depth, int Hd,
                      int Wd, double fx, double fy, double cx, double cy, double depth_scale, int po, double* out,
                      hipStream_t stream);
@@ -924,6 +931,106 @@ int ph_pose_features(ph_ctx* c, int B, int max_people, int n_parts, const int32_
     PH_CHECK(hipStreamSynchronize(s));
   }
   return 0;
+}
+
+// ---- MoveNet pre-/post-model steps -------------------------------------------------------------
+namespace {
+// host or device operand: a device copy for the duration of one call when the caller's pointer is host memory
+struct MvBuf {
+  void* dev = nullptr;
+  void* host = nullptr;
+  size_t bytes = 0;
+  bool owned = false;
+  int get(const void* p, size_t n, int on_device, bool copy_in, hipStream_t s) {
+    bytes = n;
+    if (on_device) {
+      dev = const_cast<void*>(p);
+      return 0;
+    }
+    host = const_cast<void*>(p);
+    if (hipMalloc(&dev, n ? n : 1) != hipSuccess) return -1;
+    owned = true;
+    if (copy_in && hipMemcpyAsync(dev, p, n, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    return 0;
+  }
+  int put(hipStream_t s) { return owned && hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s) != hipSuccess ? -1 : 0; }
+  ~MvBuf() {
+    if (owned && dev) (void)hipFree(dev);
+  }
+};
+}  // namespace
+
+int ph_movenet_crop_resize(ph_ctx* c, const uint8_t* frames, int B, int H, int W, const double* crop, int size,
+                           int32_t* out, int on_device) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!frames || !crop || !out || B < 1 || H < 1 || W < 1 || size < 1) {
+    ph_set_error("ph_movenet_crop_resize: bad arguments");
+    return -1;
+  }
+  hipStream_t s = c->stream;
+  MvBuf f, r, o;
+  int rc = f.get(frames, (size_t)B * H * W * 3, on_device, true, s) || r.get(crop, (size_t)B * 6 * sizeof(double), on_device, true, s) ||
+           o.get(out, (size_t)B * size * size * 3 * sizeof(int32_t), on_device, false, s);
+  if (!rc) rc = ph_launch_movenet_crop_resize((const uint8_t*)f.dev, B, H, W, (const double*)r.dev, size, (int32_t*)o.dev, s);
+  if (!rc) rc = o.put(s);
+  if (hipStreamSynchronize(s) != hipSuccess) rc = -1;
+  if (rc) ph_set_error("ph_movenet_crop_resize: allocation, launch or copy failed");
+  return rc;
+}
+
+int ph_movenet_update(ph_ctx* c, float* keypoints, const double* crop_in, int B, int image_height, int image_width,
+                      double* crop_out, int on_device) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!keypoints || !crop_in || !crop_out || B < 1 || image_height < 1 || image_width < 1) {
+    ph_set_error("ph_movenet_update: bad arguments");
+    return -1;
+  }
+  hipStream_t s = c->stream;
+  MvBuf k, ci, co;
+  int rc = k.get(keypoints, (size_t)B * 51 * sizeof(float), on_device, true, s) ||
+           ci.get(crop_in, (size_t)B * 6 * sizeof(double), on_device, true, s) ||
+           co.get(crop_out, (size_t)B * 6 * sizeof(double), on_device, false, s);
+  if (!rc) rc = ph_launch_movenet_update((float*)k.dev, (const double*)ci.dev, B, image_height, image_width, (double*)co.dev, s);
+  if (!rc) rc = k.put(s) || co.put(s);
+  if (hipStreamSynchronize(s) != hipSuccess) rc = -1;
+  if (rc) ph_set_error("ph_movenet_update: allocation, launch or copy failed");
+  return rc;
+}
+
+int ph_movenet_multipose_decode(ph_ctx* c, const float* center, const float* kpt_heat, const float* kpt_regr,
+                                const float* kpt_offs, const float* box_size, int B, int G, int max_people,
+                                float min_center, float* out, int on_device) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!center || !kpt_heat || !kpt_regr || !kpt_offs || !box_size || !out || B < 1 || G < 3 || G > 128 || max_people < 1 ||
+      max_people > 64) {
+    ph_set_error("ph_movenet_multipose_decode: bad arguments (grid 3..128, people 1..64)");
+    return -1;
+  }
+  hipStream_t s = c->stream;
+  const size_t n = (size_t)B * G * G * sizeof(float);
+  // centre list (index, score per person slot) in the ctx scratch, grown on demand
+  const size_t n_c = ((size_t)B * max_people * sizeof(int) + 255) & ~(size_t)255;
+  if (2 * n_c > c->post_bytes) {
+    PH_CHECK(hipStreamSynchronize(s));
+    if (c->post) PH_CHECK(hipFree(c->post));
+    c->post = nullptr;
+    c->post_bytes = 0;
+    PH_CHECK(hipMalloc(&c->post, 2 * n_c));
+    c->post_bytes = 2 * n_c;
+  }
+  MvBuf ce, he, re, of, bx, o;
+  int rc = ce.get(center, n, on_device, true, s) || he.get(kpt_heat, n * 17, on_device, true, s) ||
+           re.get(kpt_regr, n * 34, on_device, true, s) || of.get(kpt_offs, n * 34, on_device, true, s) ||
+           bx.get(box_size, n * 2, on_device, true, s) ||
+           o.get(out, (size_t)B * max_people * 56 * sizeof(float), on_device, false, s);
+  if (!rc)
+    rc = ph_launch_movenet_multipose((const float*)ce.dev, (const float*)he.dev, (const float*)re.dev, (const float*)of.dev,
+                                     (const float*)bx.dev, B, G, max_people, min_center, (int*)c->post,
+                                     (float*)((char*)c->post + n_c), (float*)o.dev, s);
+  if (!rc) rc = o.put(s);
+  if (hipStreamSynchronize(s) != hipSuccess) rc = -1;
+  if (rc) ph_set_error("ph_movenet_multipose_decode: allocation, launch or copy failed");
+  return rc;
 }
 
 int ph_decode_v2_connections(ph_ctx* c, int32_t* n_conn, int32_t* conn_idx, float* conn_score) {

@@ -77,6 +77,10 @@ SYMBOLS = {
     "ph_set_net_out": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int]),
     "ph_upsample_maps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ph_movenet_crop_resize": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int]),
+    "ph_movenet_update": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int]),
+    "ph_movenet_multipose_decode": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp,
+                                              C.c_int]),
     "ph_pose_features": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ph_argmax_maps": (C.c_int, [_vp, C.c_int, _vp, _vp]),
