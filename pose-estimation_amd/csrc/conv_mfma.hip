@@ -492,15 +492,14 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
                                        16, 0, 0);
     }
     const int lf = lane & 15, lq = lane >> 4;
-    bf16x8 wf[4][3];
+    // each wave owns ONE 16-channel block of the producer conv (nb = wave & 3) and every other row block
+    // (wave >> 2): 3 weight fragments per lane instead of 12 -- a quarter of the weight bytes every block
+    // pulls from L2 before it can start
+    const int nb = wave & 3;
+    bf16x8 wf[3];
 #pragma unroll
-    for (int nb = 0; nb < 4; nb++)
-#pragma unroll
-      for (int ks = 0; ks < 3; ks++)
-        wf[nb][ks] = *(const bf16x8*)(p.wt0 + (nb * 16 + lf) * p.Kpad0 + ks * 32 + lq * 8);
-    f32x4 b0[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) b0[nb] = *(const f32x4*)(p.bias0 + nb * 16 + lq * 4);
+    for (int ks = 0; ks < 3; ks++) wf[ks] = *(const bf16x8*)(p.wt0 + (nb * 16 + lf) * p.Kpad0 + ks * 32 + lq * 8);
+    const f32x4 b0 = *(const f32x4*)(p.bias0 + nb * 16 + lq * 4);
     int toff[3];
 #pragma unroll
     for (int ks = 0; ks < 3; ks++) {
@@ -518,7 +517,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     sst_[0] = sb_ - sa_;
 #endif
     prev_cnt = 0;  // everything issued so far has landed
-    for (int rb = wave; rb < 21; rb += NW) {
+    for (int rb = wave >> 2; rb < 21; rb += NW / 4) {
       const int j = rb * 16 + lf;
       const int jc = j < 324 ? j : 323;
       const int r = jc / 18, c = jc - r * 18;
@@ -528,22 +527,19 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       for (int ks = 0; ks < 3; ks++) xf[ks] = *(const bf16x8*)(src + toff[ks]);
       const int y = ty0 - 1 + r, x = tx0 - 1 + c;
       const bool inside = j < 324 && tb < p.B && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int nb = 0; nb < 4; nb++) {
-        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < 3; ks++) a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xf[ks], a0, 0, 0, 0);
+      bf16x4 o;
 #pragma unroll
-        for (int ks = 0; ks < 3; ks++) a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], xf[ks], a0, 0, 0, 0);
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          float v = a0[e] + b0[nb][e];
-          if (p.act0) v = v > 0.f ? v : 0.f;
-          o[e] = (bf16)(inside ? v : 0.f);
-        }
-        // channel nb*16 + lq*4 + e of patch pixel j: chunk nb >> 1, 16-B slot (nb & 1)*2 + (lq >> 1), swizzled
-        const int slot = ((nb & 1) * 2 + (lq >> 1)) ^ (((j >> 2) & 1) << 1);
-        *(bf16x4*)(lds + (nb >> 1) * patch_bytes + j * 64 + slot * 16 + (lq & 1) * 8) = o;
+      for (int e = 0; e < 4; e++) {
+        float v = a0[e] + b0[e];
+        if (p.act0) v = v > 0.f ? v : 0.f;
+        o[e] = (bf16)(inside ? v : 0.f);
       }
+      // channel nb*16 + lq*4 + e of patch pixel j: chunk nb >> 1, 16-B slot (nb & 1)*2 + (lq >> 1), swizzled
+      const int slot = ((nb & 1) * 2 + (lq >> 1)) ^ (((j >> 2) & 1) << 1);
+      if (j < 324) *(bf16x4*)(lds + (nb >> 1) * patch_bytes + j * 64 + slot * 16 + (lq & 1) * 8) = o;
     }
     // (the first K step's barrier makes the patch visible to every wave)
 #ifdef PH_LIN_STAMP
