@@ -308,7 +308,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // slot and the fragment offsets are compile-time constants and the loop body has no branches.
 template <int NREP, int MW, bool DBG, bool STEM = false, int TAPS = 9>  // MW waves along M x 2 along N
 __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConvParams p) {
-  constexpr bool LINC = !STEM && !DBG && TAPS == 9 && NREP >= 3 && MW == 2;  // instantiations that have the LIN loop
+  constexpr bool LINC = !STEM && !DBG && TAPS == 9 && (NREP == 4 ? MW == 2 : NREP == 3);  // instantiations with the LIN loop
   const bool LIN = LINC && p.lin;
   constexpr int BN = 32 * NREP;
   constexpr int NW = 2 * MW;                   // waves per block
@@ -624,10 +624,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #ifdef PH_LIN_STAMP
         long long cm = __builtin_readcyclecounter();
 #endif
-        if (t == 0)
-          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        PH_WAIT_VMCNT(NBW + (((t + 8) % 9) < NPC ? 1 : 0));
 #ifdef PH_LIN_STAMP
         long long c0 = __builtin_readcyclecounter();
         st[5] += c0 - cm;
