@@ -434,9 +434,10 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       // kernel choice: POSEHIP_CONV_KERNEL=0 forces the im2col-gather kernel, 4/5 the 3x3 halo-patch kernel
       // (4 / 8 waves) wherever it applies
       const char* ev = getenv("POSEHIP_CONV_KERNEL");
-      // auto: halo kernel, 8-wave blocks below 128 output channels per tile (more waves hide the
-      // per-step latency there), 4-wave blocks with 128-row wave tiles at 128
-      const int want = ev ? atoi(ev) : (o.nrep <= 3 ? 5 : 4);
+      // auto: halo kernel with 8-wave blocks (64-row wave tiles, 2 blocks per CU = 4 waves per SIMD).  With the
+      // branch-free K loop it needs no cross-step fragment prefetch and fits 128 registers at every tile width; it
+      // measured 3-8 % faster than the 4-wave / 128-row-wave-tile form on the 46x82 layers and 1-2 % on the others
+      const int want = ev ? atoi(ev) : 5;
       o.variant = want;
       p.pool = d.pool;
       if (d.pool && want != 4 && want != 5) o.variant = 4;  // only the halo kernel pools

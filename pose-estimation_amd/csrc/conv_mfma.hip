@@ -308,7 +308,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // slot and the fragment offsets are compile-time constants and the loop body has no branches.
 template <int NREP, int MW, bool DBG, bool STEM = false, int TAPS = 9>  // MW waves along M x 2 along N
 __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConvParams p) {
-  constexpr bool LINC = !STEM && !DBG && TAPS == 9 && !(NREP == 4 && MW == 4);  // instantiations with the LIN loop
+  constexpr bool LINC = !STEM && !DBG && TAPS == 9;  // instantiations with the LIN loop
   const bool LIN = LINC && p.lin;
   constexpr int BN = 32 * NREP;
   constexpr int NW = 2 * MW;                   // waves per block
