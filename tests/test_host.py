@@ -218,5 +218,41 @@ def test_compat_import_paths_resolve_to_posehip():
         assert cv.get_body_parts_and_pose_pairs("COCO")[0]["Nose"] == 0
         assert nat.PyOpenPoseNative is api_native.PyOpenPoseNative and nat.TORSO_IDS == [1, 2, 5, 8, 9, 12]
         assert nat.OpenPosePoseExtractor is api_native.OpenPosePoseExtractor
+        # the pipeline callers and their helpers (openpose/native/python/{inference,args,utils,utils_rs}.py)
+        from posehip import args as ph_args, inference as ph_inf, utils as ph_utils, utils_rs as ph_rs
+        inf = importlib.import_module("openpose.native.python.inference")
+        assert inf.extract_2dskeletons is ph_inf.extract_2dskeletons
+        assert inf.ExtractSkeletonAndTrack is ph_inf.ExtractSkeletonAndTrack
+        assert importlib.import_module("openpose.native.python.args").get_parser is ph_args.get_parser
+        assert importlib.import_module("openpose.native.python.utils").Timer is ph_utils.Timer
+        assert importlib.import_module("openpose.native.python.utils_rs").read_color_file is ph_rs.read_color_file
     finally:
         sys.path.remove(os.path.join(root, "compat"))
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under pose-estimation_amd/ or compat/ may import, open or
+    execute it (only tests/, smoke() and bench.py's cpu_baseline leg do)."""
+    import ast
+    hits = []
+    for top in ("pose-estimation_amd", "compat"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for fn in files:
+                if not fn.endswith(".py"):
+                    continue
+                path = os.path.join(dirpath, fn)
+                tree = ast.parse(open(path).read(), path)
+                for node in ast.walk(tree):
+                    names = []
+                    if isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        names = [node.module or ""]
+                    elif isinstance(node, ast.Call) and getattr(node.func, "id", getattr(node.func, "attr", "")) in (
+                            "import_module", "__import__", "exec", "eval"):
+                        names = [a.value for a in node.args if isinstance(a, ast.Constant) and isinstance(a.value, str)]
+                    hits += [(path, n) for n in names if n == "oracle" or n.startswith("oracle.")]
+    assert not hits, hits
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pose-estimation_amd", "csrc")):
+        for fn in files:
+            assert "#include \"../../oracle" not in open(os.path.join(dirpath, fn)).read()
