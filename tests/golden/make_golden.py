@@ -115,7 +115,13 @@ def callers():
             truth[v] = utils.str2bool(v)
         except Exception as e:
             truth[v] = type(e).__name__
-    meta = {"flags": flags, "str2bool": truth,
+    spec = importlib.util.spec_from_file_location("ref_movenet_common", "/root/reference/movenet/common.py")
+    mvc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mvc)                                  # constants only (movenet/common.py)
+    movenet = {"KEYPOINT_DICT": mvc.KEYPOINT_DICT, "MODEL_URL": mvc.MODEL_URL,
+               "MIN_CROP_KEYPOINT_SCORE": mvc.MIN_CROP_KEYPOINT_SCORE,
+               "KEYPOINT_EDGE_INDS_TO_COLOR": [[a, b, c] for (a, b), c in mvc.KEYPOINT_EDGE_INDS_TO_COLOR.items()]}
+    meta = {"movenet_common": movenet, "flags": flags, "str2bool": truth,
             "get_color": [list(utils.get_color(i)) for i in range(12)],
             "get_color_fast": [list(utils.get_color_fast(i)) for i in range(12)]}
     with open(os.path.join(HERE, "callers_ref.json"), "w") as f:

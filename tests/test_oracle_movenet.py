@@ -96,3 +96,17 @@ def test_multipose_decode_specification_case():
     assert out[1, 51 + 0] == 5 / 8 and out[1, 52] == 5 / 8 and out[2, 52] == 6 / 8
     assert np.allclose(out[1, :51].reshape(17, 3)[:, 2], 0.7)
     assert not out[3].any()                                             # only three centres above min_center
+
+
+def test_constants_match_the_reference_file():
+    """movenet/common.py is constants only and imports here: tests/golden/callers_ref.json holds its values."""
+    import json
+    import os
+    from posehip import movenet as pmv
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "callers_ref.json")) as f:
+        ref = json.load(f)["movenet_common"]
+    edges = {(a, b): c for a, b, c in ref["KEYPOINT_EDGE_INDS_TO_COLOR"]}
+    for mod in (mv, pmv):
+        assert mod.KEYPOINT_DICT == ref["KEYPOINT_DICT"]
+        assert mod.MIN_CROP_KEYPOINT_SCORE == ref["MIN_CROP_KEYPOINT_SCORE"]
+    assert pmv.MODEL_URL == ref["MODEL_URL"] and pmv.KEYPOINT_EDGE_INDS_TO_COLOR == edges
