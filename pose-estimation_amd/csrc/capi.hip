@@ -29,6 +29,7 @@ int ph_launch_movenet_update(float* kp, const double* crop_in, int B, int ih, in
 int ph_launch_movenet_multipose(const float* center, const float* heat, const float* regr, const float* offs,
                                 const float* boxs, int B, int G, int maxp, float min_center, int* c_idx,
                                 float* c_score, float* out, hipStream_t stream);
+int ph_conv_1x1_mw();
 int ph_launch_lift3d(const float* kp, const int* n_people, int B, int maxp, int J, const uint16_t* depth, int Hd,
                      int Wd, double fx, double fy, double cx, double cy, double depth_scale, int po, double* out,
                      hipStream_t stream);
@@ -599,7 +600,7 @@ int ph_op_kernel(ph_ctx* c, int op, char* name, int cap) {
   if (o.skip) snprintf(name, cap, "(fused into the next op)");
   else if (o.d.type == PH_OP_POOL) snprintf(name, cap, "maxpool2x2_kernel");
   else if (o.cp.stem) snprintf(name, cap, "conv3x3_halo_kernel<2, 4, false, true, 9>");
-  else if (o.variant == 6) snprintf(name, cap, "conv3x3_halo_kernel<%d, 2, false, false, 1>", o.nrep);
+  else if (o.variant == 6) snprintf(name, cap, "conv3x3_halo_kernel<%d, %d, false, false, 1>", o.nrep, ph_conv_1x1_mw());
   else if (o.variant == 4 || o.variant == 5)
     snprintf(name, cap, "conv3x3_halo_kernel<%d, %d, %s, false, 9>", o.nrep, o.variant == 5 ? 4 : 2,
              o.cp.debug ? "true" : "false");
