@@ -6,7 +6,7 @@
 
 One process per GPU (the driver launches N>1 through torch.distributed.run);
 frames shard independently across ranks, no collective in the compute path,
-RCCL only gathers the padded keypoint tensors to rank 0 once per step.  A step
+one RCCL all_gather of the packed, padded keypoint records per step.  A step
 is one batch of 32 synthetic frames per GPU, already resident in HBM:
   u8 frames -> ph_preprocess -> ph_forward (MFMA implicit-GEMM convs) ->
   ph_decode_v2 (upsample+NMS, PAF matching, assembly) -> keypoints to host.
@@ -68,6 +68,12 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when its first communicator
+    # comes up, so everything but the result line is sent to stderr at the descriptor level.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from posehip import _ffi, caffe_io, graph
@@ -82,11 +88,16 @@ def main():
     # POSEHIP_BENCH_BACKEND=gloo + several ranks on one card rehearses the N > 1 control flow on a 1-GPU box
     backend = os.environ.get("POSEHIP_BENCH_BACKEND", "nccl")
     local_rank %= torch.cuda.device_count()
+    # POSEHIP_BENCH_FORCE_GATHER=1 runs the RCCL gather path with a one-rank group (rehearsal on a 1-GPU box)
+    gather = world > 1 or bool(os.environ.get("POSEHIP_BENCH_FORCE_GATHER"))
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    elif gather:
+        dist.init_process_group(backend, init_method="tcp://127.0.0.1:29531", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank) if backend == "nccl" else None)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B = args.batch
@@ -119,17 +130,24 @@ def main():
              "n": torch.empty((B,), dtype=torch.int32).pin_memory(),
              "kp": torch.empty((B, MAX_PEOPLE, J, 3), dtype=torch.float32).pin_memory(),
              "sc": torch.empty((B, MAX_PEOPLE), dtype=torch.float32).pin_memory()}
-        if world > 1:  # 39 KB/frame: latency-bound, far below one xGMI link
-            d["gn"] = torch.empty((B,), dtype=torch.int32, device=dev)
-            d["gkp"] = torch.empty((B, MAX_PEOPLE, J, 3), dtype=torch.float32, device=dev)
-            d["gsc"] = torch.empty((B, MAX_PEOPLE), dtype=torch.float32, device=dev)
+        if gather:  # 39 KB/frame: latency-bound, far below one xGMI link
+            # one packed record per rank and step (keypoints | scores | counts), so ONE collective per step
+            n_kp, n_sc = B * MAX_PEOPLE * J * 3, B * MAX_PEOPLE
+            d["pack"] = torch.empty((n_kp + n_sc + B,), dtype=torch.float32, device=dev)
+            d["gkp"] = d["pack"][:n_kp].view(B, MAX_PEOPLE, J, 3)
+            d["gsc"] = d["pack"][n_kp:n_kp + n_sc].view(B, MAX_PEOPLE)
+            d["gn"] = d["pack"][n_kp + n_sc:].view(torch.int32)
         bufs.append(d)
     g = {}
-    if world > 1:
+    if gather:
         gdev = dev if backend == "nccl" else torch.device("cpu")
-        g["N"] = torch.empty((world * B,), dtype=torch.int32, device=gdev)
-        g["KP"] = torch.empty((world * B, MAX_PEOPLE, J, 3), dtype=torch.float32, device=gdev)
-        g["SC"] = torch.empty((world * B, MAX_PEOPLE), dtype=torch.float32, device=gdev)
+        if backend == "nccl":   # one gathered record set per engine: gathers of different engines may overlap
+            for d in bufs:
+                d["gpack"] = torch.empty((world, d["pack"].numel()), dtype=torch.float32, device=gdev)
+        else:
+            g["N"] = torch.empty((world * B,), dtype=torch.int32, device=gdev)
+            g["KP"] = torch.empty((world * B, MAX_PEOPLE, J, 3), dtype=torch.float32, device=gdev)
+            g["SC"] = torch.empty((world * B, MAX_PEOPLE), dtype=torch.float32, device=gdev)
     cur = torch.cuda.current_stream()
     trace = (lambda *a: print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)) if os.environ.get("BENCH_TRACE") \
         else (lambda *a: None)
@@ -140,8 +158,6 @@ def main():
         k = i % S
         e, ts, d = engs[k], tstreams[k], bufs[k]
         ts.synchronize()           # the batch this engine ran S steps ago has delivered its keypoints
-        if world > 1:
-            ts.wait_stream(cur)    # ... and its all_gather has read the device result buffers
         if args.h2d:
             with torch.cuda.stream(ts):
                 d["frames"].copy_(frames_host, non_blocking=True)
@@ -150,13 +166,14 @@ def main():
         e.decode_v2_dev(BODY_25, B, NET_H, NET_W, kp_scale, MAX_PEOPLE)
         # results to pinned host memory (rank-local) ...
         e.decode_v2_results(d["n"], d["kp"], d["sc"])
-        if world > 1 and backend == "nccl":  # ... and one RCCL all_gather of the padded tensors (rank 0 keeps it)
+        if gather and backend == "nccl":  # ... and one RCCL all_gather of the padded tensors (rank 0 keeps it)
             e.decode_v2_results(d["gn"], d["gkp"], d["gsc"])
-            cur.wait_stream(ts)
-            dist.all_gather_into_tensor(g["N"], d["gn"])
-            dist.all_gather_into_tensor(g["KP"], d["gkp"])
-            dist.all_gather_into_tensor(g["SC"], d["gsc"])
-        elif world > 1:  # rehearsal backend (gloo): same control flow, gather of the host copies
+            # Issued with the ENGINE's stream current: the collective waits for this batch's decode only, and
+            # only this engine's next batch waits for the collective.  (Issuing every gather from one common
+            # stream and making the engines wait for that stream serializes the batches in flight: -12 %.)
+            with torch.cuda.stream(ts):
+                dist.all_gather_into_tensor(d["gpack"], d["pack"])
+        elif gather:  # rehearsal backend (gloo): same control flow, gather of the host copies
             ts.synchronize()
             dist.all_gather_into_tensor(g["N"], d["n"])
             dist.all_gather_into_tensor(g["KP"], d["kp"])
@@ -274,8 +291,9 @@ def main():
         }
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(net, weights, BODY_25, args.cpu_frames, 1000)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+    if gather:
         dist.destroy_process_group()
 
 
