@@ -163,9 +163,10 @@ def main():
                 d["frames"].copy_(frames_host, non_blocking=True)
         e.preprocess(d["frames"], _ffi.PH_PRE_NATIVE)
         e.forward(B)
-        e.decode_v2_dev(BODY_25, B, NET_H, NET_W, kp_scale, MAX_PEOPLE)
-        # results to pinned host memory (rank-local) ...
-        e.decode_v2_results(d["n"], d["kp"], d["sc"])
+        if not os.environ.get("BENCH_DIAG_NO_DECODE"):   # diagnostic only: what the decode costs end to end
+            e.decode_v2_dev(BODY_25, B, NET_H, NET_W, kp_scale, MAX_PEOPLE)
+            # results to pinned host memory (rank-local) ...
+            e.decode_v2_results(d["n"], d["kp"], d["sc"])
         if gather and backend == "nccl":  # ... and one RCCL all_gather of the padded tensors (rank 0 keeps it)
             e.decode_v2_results(d["gn"], d["gkp"], d["gsc"])
             # Issued with the ENGINE's stream current: the collective waits for this batch's decode only, and

@@ -26,6 +26,14 @@
 
 // Timing experiments only (PhConvParams::debug & 8): per-phase cycle sums over all blocks.
 __device__ unsigned long long ph_conv_dbg[8];
+#ifdef PH_TIMELINE
+// Diagnostic build only (tools/conv_timeline.py): per block of the last branch-free 3x3 launch, the 100 MHz
+// s_memrealtime at kernel entry, K loop start, K loop end and after the last store has been issued, + the CU id.
+__device__ unsigned long long ph_conv_tl[4096 * 5];
+extern "C" int ph_debug_conv_timeline(unsigned long long* out, int nblocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ph_conv_tl), (size_t)nblocks * 5 * sizeof(unsigned long long));
+}
+#endif
 extern "C" int ph_debug_conv_cycles(unsigned long long* out, int reset) {
   if (reset) {
     unsigned long long z[8] = {0};
@@ -341,6 +349,10 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   const long long s0_ = __builtin_readcyclecounter();
   long long sst_[4] = {0, 0, 0, 0};
 #endif
+#ifdef PH_TIMELINE
+  const unsigned long long tl0_ = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tl1_ = 0, tl2_ = 0;
+#endif
 
   const unsigned nblk = gridDim.x;
   const unsigned bid = blockIdx.x;
@@ -608,6 +620,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     const char* const bb0 = bring + b_rd;
     const int astep = SI * 64;  // row block i of a tap sits SI pixels further on (SI = 16 or 24: the swizzle bit, bit 2
                                 // of the pixel index, is the same for every i)
+#ifdef PH_TIMELINE
+    tl1_ = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef PH_LIN_STAMP
     long long st[6] = {0, 0, 0, 0, 0, 0};
     const long long m0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
@@ -674,6 +689,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetches past the end of K
+#ifdef PH_TIMELINE
+    tl2_ = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef PH_LIN_STAMP
     if (lane == 0 && wave == 1 && !p.debug_epi) {
       for (int k = 0; k < 6; k++) atomicAdd(&ph_conv_dbg[k], (unsigned long long)st[k]);
@@ -943,6 +961,14 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     atomicAdd(&ph_conv_dbg[7], 1ull);
     atomicAdd(&ph_conv_dbg[4], (unsigned long long)(sk_ - s0_));   // start .. end of K loop
     atomicAdd(&ph_conv_dbg[5], (unsigned long long)(se2_ - sk_));  // epilogue
+  }
+#endif
+#ifdef PH_TIMELINE
+  if (LINC && LIN && lane == 0 && wave == 0 && blockIdx.x < 4096) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned long long* o = ph_conv_tl + blockIdx.x * 5;
+    o[0] = tl0_; o[1] = tl1_; o[2] = tl2_; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = hwid;
   }
 #endif
   if (dbg_t) {

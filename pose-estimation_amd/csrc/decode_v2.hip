@@ -119,6 +119,176 @@ __global__ __launch_bounds__(NMS_TX * NMS_TY) void nms_detect_kernel(const float
 }
 
 // ---------------------------------------------------------------------------
+// kernel 1a, column form (the default): same outputs as nms_detect_kernel, no upsampled pixel ever goes through
+// LDS.  A lane owns one output column and walks down the stripe: the four horizontally interpolated source rows
+// of the current vertical taps and the cubic's coefficients live in registers (they change once per source row,
+// i.e. every `scale` output rows), an output pixel is the 8 fp32 operations of the cubic in d -- the very
+// operations of cubic(), so results are bit-identical -- and the 3x3 test takes the column maxima of the two
+// neighbouring lanes by shuffle.  A wave covers 64 consecutive columns of which lanes 1..62 emit (lanes 0 and 63
+// only feed their neighbours); a wave owns up to G such column groups.  Block-wide work is only the ordering of a
+// band's peaks (as above).
+// ---------------------------------------------------------------------------
+#define NMS_COLS 62
+// value of lane-1 / lane+1 across the whole wave (DPP wave shifts: no LDS round trip); the end lanes keep `v`
+__device__ __forceinline__ float lane_left(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_right(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+template <int G>
+__global__ __launch_bounds__(1024) void nms_detect_cols_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
+                                                               int Ht, int Wt, float threshold, int max_peaks,
+                                                               int n_parts, int n_split, int rows_per_split,
+                                                               int n_groups, int* __restrict__ keys,
+                                                               int* __restrict__ key_cnt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int part = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+  const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = NT >> 6;
+  float* s_src = smem;                                        // hs*ws
+  TapsP* s_yt = (TapsP*)(s_src + hs * ws);                    // rows_per_split + 2: vertical taps of every row
+  int* s_seg = (int*)(s_yt + rows_per_split + 2);             // rows_per_split + 3: last row of the run of rows
+                                                              // with the same four source rows that starts at i
+  int* s_cand = s_seg + rows_per_split + 3;                   // (NMS_BAND/2) * (Wt/2+1)
+  int* s_keys = s_cand + (NMS_BAND / 2) * (Wt / 2 + 1);       // max_peaks
+  __shared__ int s_ncand;
+
+  const int y_begin = sp * rows_per_split;
+  const int y_end = y_begin + rows_per_split < Ht ? y_begin + rows_per_split : Ht;
+  const int yo_first = y_begin < 1 ? 1 : y_begin;             // output rows: 1-px image border excluded
+  const int yo_last = y_end - 1 > Ht - 2 ? Ht - 2 : y_end - 1;
+  const int ylo = yo_first - 1;                               // upsampled rows [ylo, yo_last + 1] are evaluated
+  const int n_u = yo_last + 2 - ylo;
+  int* out = keys + (((size_t)b * n_parts + part) * n_split + sp) * max_peaks;
+  if (yo_first > yo_last) {                                   // (block-uniform)
+    if (tid == 0) key_cnt[((size_t)b * n_parts + part) * n_split + sp] = 0;
+    return;
+  }
+  const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
+  for (int i = tid; i < hs * ws; i += NT) s_src[i] = plane[i];
+  for (int i = tid; i < n_u; i += NT) s_yt[i] = pack_taps(src_taps(ylo + i, Ht, hs));
+  if (tid == 0) s_ncand = 0;
+
+  int xcol[G];
+  bool emit[G];
+  TapsP tx[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const int gi = wave + g * n_waves;
+    const int x = gi * NMS_COLS + lane - 1;
+    xcol[g] = x;
+    emit[g] = gi < n_groups && lane >= 1 && lane <= NMS_COLS && x >= 1 && x <= Wt - 2;
+    const int xc = x < 0 ? 0 : (x > Wt - 1 ? Wt - 1 : x);
+    tx[g] = pack_taps(src_taps(xc, Wt, ws));
+  }
+  __syncthreads();
+  for (int i = tid; i < n_u; i += NT) {                       // run ends (runs are <= ceil(scale) rows long)
+    const TapsP t = s_yt[i];
+    int e = i;
+    while (e + 1 < n_u) {
+      const TapsP u = s_yt[e + 1];
+      if (u.i0 != t.i0 || u.i1 != t.i1 || u.i2 != t.i2 || u.i3 != t.i3) break;
+      e++;
+    }
+    s_seg[i] = e;
+  }
+  __syncthreads();
+
+  int ti0 = -1, ti1 = -1, ti2 = -1, ti3 = -1;                 // source rows held in tv[][0..3] (block-uniform)
+  float tv[G][4], ca[G], cb[G], cc[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) tv[g][0] = tv[g][1] = tv[g][2] = tv[g][3] = ca[g] = cb[g] = cc[g] = 0.f;
+  // the four source rows of upsampled row index i (relative to ylo) -> registers, cubic()'s a, b, c of them
+  auto load_taps = [&](int i) {
+    const TapsP ty = s_yt[i];
+    const int n0 = __builtin_amdgcn_readfirstlane((int)ty.i0), n1 = __builtin_amdgcn_readfirstlane((int)ty.i1);
+    const int n2 = __builtin_amdgcn_readfirstlane((int)ty.i2), n3 = __builtin_amdgcn_readfirstlane((int)ty.i3);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      auto pick = [&](int nk) -> float {
+        if (nk == ti0) return tv[g][0];
+        if (nk == ti1) return tv[g][1];
+        if (nk == ti2) return tv[g][2];
+        if (nk == ti3) return tv[g][3];
+        return cubic_row(s_src + nk * ws, tx[g]);
+      };
+      const float v0 = pick(n0), v1 = pick(n1), v2 = pick(n2), v3 = pick(n3);
+      tv[g][0] = v0; tv[g][1] = v1; tv[g][2] = v2; tv[g][3] = v3;
+      ca[g] = (((-0.5f * v0 + 1.5f * v1) - 1.5f * v2) + 0.5f * v3);   // cubic()'s a, b, c
+      cb[g] = (((v0 - 2.5f * v1) + 2.0f * v2) - 0.5f * v3);
+      cc[g] = 0.5f * (v0 - v2);
+    }
+    ti0 = n0; ti1 = n1; ti2 = n2; ti3 = n3;
+    return __builtin_amdgcn_readfirstlane(s_seg[i]);
+  };
+  auto u_val = [&](int g, float d) { return ((((ca[g] * d) * d) * d + (cb[g] * d) * d) - cc[g] * d) + tv[g][1]; };
+
+  float up[G], uc[G];
+  int seg_last = load_taps(0);                                // rows are indexed relative to ylo from here on
+  {
+    const float d0 = s_yt[0].d;
+#pragma unroll
+    for (int g = 0; g < G; g++) up[g] = u_val(g, d0);
+  }
+  if (seg_last < 1) seg_last = load_taps(1);
+  {
+    const float d1 = s_yt[1].d;
+#pragma unroll
+    for (int g = 0; g < G; g++) uc[g] = u_val(g, d1);
+  }
+  const int i_last = yo_last - ylo;                           // output rows are i = 1 .. i_last
+  int key_row = yo_first * Wt;
+  int base = 0;      // peaks found so far in this stripe (uniform across the block)
+  for (int i = 1; i <= i_last && base < max_peaks;) {
+    const int band_last = i + NMS_BAND - 1 < i_last ? i + NMS_BAND - 1 : i_last;
+    float dd[NMS_BAND];                                       // the band's vertical phases: one LDS wait per band
+#pragma unroll
+    for (int r = 0; r < NMS_BAND; r++) dd[r] = s_yt[i + 1 + r < n_u ? i + 1 + r : n_u - 1].d;
+#pragma unroll
+    for (int r = 0; r < NMS_BAND; r++) {
+      if (i > band_last) break;
+      if (i + 1 > seg_last) seg_last = load_taps(i + 1);
+      const float d = dd[r];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        if (G > 1 && wave + g * n_waves >= n_groups) continue;
+        const float un = u_val(g, d);
+        // column maximum of the 3 rows; NaN if any is NaN (then `v > m` is false, as `v > NaN` is in the 8 tests)
+        float m3 = fmaxf(fmaxf(up[g], uc[g]), un);
+        if (up[g] != up[g] || uc[g] != uc[g] || un != un) m3 = __builtin_nanf("");
+        const float ml = lane_left(m3), mr = lane_right(m3);
+        const float v = uc[g];
+        if (emit[g] && v > threshold && v > up[g] && v > un && v > ml && v > mr) {
+          const int slot = atomicAdd(&s_ncand, 1);
+          s_cand[slot] = key_row + xcol[g];
+        }
+        up[g] = v;
+        uc[g] = un;
+      }
+      key_row += Wt;
+      i++;
+    }
+    __syncthreads();
+    // raster order inside the band by rank; keep the first max_peaks of the stripe
+    const int n = s_ncand;
+    for (int k = tid; k < n; k += NT) {
+      const int key = s_cand[k];
+      int rank = 0;
+      for (int j = 0; j < n; j++) rank += s_cand[j] < key;
+      if (base + rank < max_peaks) s_keys[base + rank] = key;
+    }
+    base += n;
+    __syncthreads();
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+  }
+  const int count = base < max_peaks ? base : max_peaks;
+  for (int k = tid; k < count; k += NT) out[k] = s_keys[k];
+  if (tid == 0) key_cnt[((size_t)b * n_parts + part) * n_split + sp] = count;
+}
+
+// ---------------------------------------------------------------------------
 // kernel 1b: concatenate the stripes' peak lists (raster order, first
 // max_peaks), 7x7 score-weighted centroid.  grid (n_parts, B), block 128
 // ---------------------------------------------------------------------------
@@ -710,8 +880,19 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   }
   const int n_split = PH_V2_NMS_SPLIT;
   const int rows_per_split = (((Ht + n_split - 1) / n_split) + NMS_BAND - 1) / NMS_BAND * NMS_BAND;
-  const size_t lds1 = ((size_t)hs * ws + (size_t)NMS_TRING * Wt + (size_t)(NMS_BAND + 2) * Wt) * 4 +
-                      (size_t)Wt * sizeof(TapsP) + ((size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4;
+  // POSEHIP_NMS_BANDS=1: the first form of kernel 1a (upsampled bands through LDS), kept for A/B runs
+  static const bool nms_bands = [] { const char* e = getenv("POSEHIP_NMS_BANDS"); return e && atoi(e) != 0; }();
+  const int n_groups = (Wt - 1 + NMS_COLS - 1) / NMS_COLS;          // 62 output columns per wave and group
+  const int nms_g = n_groups <= 16 ? 1 : (n_groups <= 32 ? 2 : 4);
+  const int nms_waves = (n_groups + nms_g - 1) / nms_g;
+  if (!nms_bands && nms_waves > 16) {
+    ph_set_error("decode_v2: target width %d beyond the NMS kernel's %d columns", Wt, 64 * NMS_COLS);
+    return -1;
+  }
+  const size_t lds1 = nms_bands ? ((size_t)hs * ws + (size_t)NMS_TRING * Wt + (size_t)(NMS_BAND + 2) * Wt) * 4 +
+                          (size_t)Wt * sizeof(TapsP) + ((size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4
+                                : (size_t)hs * ws * 4 + (size_t)(rows_per_split + 2) * sizeof(TapsP) +
+                          ((size_t)(rows_per_split + 3) + (size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4;
   const size_t lds1b = (size_t)hs * ws * 4;
   const size_t lds2 = (size_t)PAF_LIST_CAP * 8 + ((size_t)2 * hs * ws + (size_t)2 * (m.max_peaks + 1) * 3) * 4 +
                       (size_t)(Wt + Ht + 1) * sizeof(TapsP) + (size_t)3 * (m.max_peaks + 1) * 8 +
@@ -726,7 +907,11 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
     return -1;
   }
   static int attr[4][PH_MAX_DEVICES];
+  static int attr_c[3][PH_MAX_DEVICES];
   if (ph_ensure_lds((const void*)nms_detect_kernel, (int)lim, attr[0]) ||
+      ph_ensure_lds((const void*)nms_detect_cols_kernel<1>, (int)lim, attr_c[0]) ||
+      ph_ensure_lds((const void*)nms_detect_cols_kernel<2>, (int)lim, attr_c[1]) ||
+      ph_ensure_lds((const void*)nms_detect_cols_kernel<4>, (int)lim, attr_c[2]) ||
       ph_ensure_lds((const void*)nms_refine_kernel, (int)lim, attr[1]) ||
       ph_ensure_lds((const void*)paf_match_kernel, (int)lim, attr[2]) ||
       ph_ensure_lds((const void*)assemble_kernel, (int)lim, attr[3]))
@@ -736,8 +921,16 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   PH_CHECK(hipMemsetAsync(w.peaks, 0, sz.peaks, stream));
   PH_CHECK(hipMemsetAsync(w.overflow, 0, sizeof(int), stream));
   if (ev) PH_CHECK(hipEventRecord(ev[0], stream));
-  hipLaunchKernelGGL(nms_detect_kernel, dim3(m.n_parts, B, n_split), dim3(NMS_TX, NMS_TY), lds1, stream, net_out, C, hs, ws, Ht,
-                     Wt, m.nms_threshold, m.max_peaks, m.n_parts, n_split, rows_per_split, w.nms_keys, w.nms_cnt);
+  if (nms_bands) {
+    hipLaunchKernelGGL(nms_detect_kernel, dim3(m.n_parts, B, n_split), dim3(NMS_TX, NMS_TY), lds1, stream, net_out, C,
+                       hs, ws, Ht, Wt, m.nms_threshold, m.max_peaks, m.n_parts, n_split, rows_per_split, w.nms_keys,
+                       w.nms_cnt);
+  } else {
+    auto kern = nms_g == 1 ? nms_detect_cols_kernel<1> : (nms_g == 2 ? nms_detect_cols_kernel<2> : nms_detect_cols_kernel<4>);
+    hipLaunchKernelGGL(kern, dim3(m.n_parts, B, n_split), dim3(64 * nms_waves), lds1, stream, net_out, C, hs, ws, Ht,
+                       Wt, m.nms_threshold, m.max_peaks, m.n_parts, n_split, rows_per_split, n_groups, w.nms_keys,
+                       w.nms_cnt);
+  }
   hipLaunchKernelGGL(nms_refine_kernel, dim3(m.n_parts, B), dim3(128), lds1b, stream, net_out, C, hs, ws, Ht, Wt,
                      m.max_peaks, m.n_parts, n_split, (const int*)w.nms_keys, (const int*)w.nms_cnt, w.peaks);
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
