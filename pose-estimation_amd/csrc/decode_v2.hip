@@ -356,8 +356,36 @@ __device__ __forceinline__ int pir(float x) { return (int)(x + 0.5f); }
 #define PAF_LIST_CAP 2048
 #define PAF_THREADS 1024
 
-__device__ float score_ab(const float* A, const float* Bp, const float* mapx, const float* mapy, int ws, int Ht,
-                          int Wt, const TapsP* xt, const TapsP* yt, float inter_thr, float inter_min_above,
+// One cubic_row() from a table of its coefficients: cubic()'s a, b, c and v1 depend on the source row and the
+// centre tap only (the other taps follow from it by clamping), so they are computed once per source pixel and a
+// sample costs one 16-byte LDS read + the 8 operations in d per row instead of 4 reads + 24 operations.  Same
+// operations on the same values as cubic_row(): bit-identical.
+__device__ __forceinline__ float4 cubic_coef(const float* __restrict__ row, int c, int ws) {
+  const int i0 = c - 1 < 0 ? 0 : c - 1, i2 = c + 1 > ws - 1 ? ws - 1 : c + 1, i3 = i2 + 1 > ws - 1 ? ws - 1 : i2 + 1;
+  const float v0 = row[i0], v1 = row[c], v2 = row[i2], v3 = row[i3];
+  float4 q;
+  q.x = (((-0.5f * v0 + 1.5f * v1) - 1.5f * v2) + 0.5f * v3);
+  q.y = (((v0 - 2.5f * v1) + 2.0f * v2) - 0.5f * v3);
+  q.z = 0.5f * (v0 - v2);
+  q.w = v1;
+  return q;
+}
+__device__ __forceinline__ float cubic_row_cf(const float4* row, int i1, float d) {
+  const float4 q = row[i1];
+  return ((((q.x * d) * d) * d + (q.y * d) * d) - q.z * d) + q.w;
+}
+__device__ __forceinline__ float bicubic_cf(const float4* tab, int ws, const TapsP& tx, const TapsP& ty) {
+  const float t0 = cubic_row_cf(tab + ty.i0 * ws, tx.i1, tx.d), t1 = cubic_row_cf(tab + ty.i1 * ws, tx.i1, tx.d);
+  const float t2 = cubic_row_cf(tab + ty.i2 * ws, tx.i1, tx.d), t3 = cubic_row_cf(tab + ty.i3 * ws, tx.i1, tx.d);
+  return cubic(t0, t1, t2, t3, ty.d);
+}
+
+// COEF: mapx / mapy are float4 coefficient tables (above), else the raw planes.
+// kmin[n] = the smallest count k with (float)k / (float)n > inter_min_above (n + 1 if none): upstream's acceptance
+// test and the "can no longer pass" test below are that comparison, which is monotone in k.
+template <bool COEF>
+__device__ float score_ab(const float* A, const float* Bp, const void* mapx, const void* mapy, int ws, int Ht,
+                          int Wt, const TapsP* xt, const TapsP* yt, float inter_thr, const unsigned char* kmin,
                           double close_thr, float close_score) {
   const float vx = Bp[0] - A[0];
   const float vy = Bp[1] - A[1];
@@ -373,10 +401,11 @@ __device__ float score_ab(const float* A, const float* Bp, const float* mapx, co
     int count = 0;
     const float fn = (float)npts;
     const float stepx = vx / fn, stepy = vy / fn;
+    const int need = kmin[npts];
     bool alive = true;
     for (int lm = 0; lm < npts; lm++) {
       // the acceptance test below can no longer pass: the sum is not needed (same result, less work)
-      if (!((float)(count + npts - lm) / fn > inter_min_above)) {
+      if (count + npts - lm < need) {
         alive = false;
         break;
       }
@@ -387,20 +416,21 @@ __device__ float score_ab(const float* A, const float* Bp, const float* mapx, co
       my = my > Ht - 1 ? Ht - 1 : my;
       my = my < 0 ? 0 : my;
       const TapsP tx = xt[mx], ty = yt[my];
-      const float px = bicubic_tp(mapx, ws, tx, ty);
-      const float py = bicubic_tp(mapy, ws, tx, ty);
+      const float px = COEF ? bicubic_cf((const float4*)mapx, ws, tx, ty) : bicubic_tp((const float*)mapx, ws, tx, ty);
+      const float py = COEF ? bicubic_cf((const float4*)mapy, ws, tx, ty) : bicubic_tp((const float*)mapy, ws, tx, ty);
       const float s = nx * px + ny * py;
       if (s > inter_thr) {
         total = total + s;
         count++;
       }
     }
-    if (alive && (float)count / fn > inter_min_above) return total / (float)count;
+    if (alive && count >= need) return total / (float)count;
     if ((double)norm < close_thr) return close_score;
   }
   return 0.f;
 }
 
+template <bool COEF>
 __global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
                                                         int Ht, int Wt, const float* __restrict__ peaks,
                                                         PhV2Dev mdl, float* __restrict__ pair_scores,
@@ -418,10 +448,11 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __r
     if (tid == 0) *out_n = 0;
     return;
   }
+  constexpr int PLANE_WORDS = COEF ? 4 : 1;                // floats per source pixel and channel
   unsigned long long* s_list = (unsigned long long*)smem;  // PAF_LIST_CAP accepted (score, i, j) keys
-  float* s_mx = (float*)(s_list + PAF_LIST_CAP);
-  float* s_my = s_mx + hs * ws;
-  float* s_A = s_my + hs * ws;  // P1*3
+  float* s_mx = (float*)(s_list + PAF_LIST_CAP);           // (16-byte aligned: PAF_LIST_CAP * 8 bytes in)
+  float* s_my = s_mx + hs * ws * PLANE_WORDS;
+  float* s_A = s_my + hs * ws * PLANE_WORDS;  // P1*3
   float* s_B = s_A + P1 * 3;
   TapsP* s_xt = (TapsP*)(s_B + P1 * 3);  // Wt
   TapsP* s_yt = s_xt + Wt;               // Ht
@@ -432,12 +463,19 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __r
   unsigned char* s_occB = s_occA + P1;
   __shared__ unsigned long long s_best;
   __shared__ int s_count, s_nlist;
+  __shared__ unsigned char s_kmin[32];
 
   const float* px = net_out + ((size_t)b * C + mdl.n_heat + mdl.mapidx[2 * pair]) * hs * ws;
   const float* py = net_out + ((size_t)b * C + mdl.n_heat + mdl.mapidx[2 * pair + 1]) * hs * ws;
   for (int i = tid; i < hs * ws; i += PAF_THREADS) {
-    s_mx[i] = px[i];
-    s_my[i] = py[i];
+    if (COEF) {
+      const int r = i / ws, c = i - r * ws;
+      ((float4*)s_mx)[i] = cubic_coef(px + r * ws, c, ws);
+      ((float4*)s_my)[i] = cubic_coef(py + r * ws, c, ws);
+    } else {
+      s_mx[i] = px[i];
+      s_my[i] = py[i];
+    }
   }
   for (int i = tid; i < P1 * 3; i += PAF_THREADS) {
     s_A[i] = candA[i];
@@ -449,6 +487,11 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __r
   }
   for (int x = tid; x < Wt; x += PAF_THREADS) s_xt[x] = pack_taps(src_taps(x, Wt, ws));
   for (int y = tid; y < Ht; y += PAF_THREADS) s_yt[y] = pack_taps(src_taps(y, Ht, hs));
+  if (tid < 32) {  // sample counts are 5..25
+    int k = 0;
+    while (k <= tid && !((float)k / (float)tid > mdl.inter_min_above)) k++;
+    s_kmin[tid] = (unsigned char)k;
+  }
   if (tid == 0) {
     s_best = 0ull;
     s_count = 0;
@@ -460,8 +503,8 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __r
   const int npairs = nA * nB;
   for (int p = tid; p < npairs; p += PAF_THREADS) {
     const int i = p / nB, j = p - i * nB;  // 0-based
-    const float s = score_ab(s_A + (i + 1) * 3, s_B + (j + 1) * 3, s_mx, s_my, ws, Ht, Wt, s_xt, s_yt,
-                             mdl.inter_threshold, mdl.inter_min_above, mdl.close_thr, mdl.close_score);
+    const float s = score_ab<COEF>(s_A + (i + 1) * 3, s_B + (j + 1) * 3, s_mx, s_my, ws, Ht, Wt, s_xt, s_yt,
+                                   mdl.inter_threshold, s_kmin, mdl.close_thr, mdl.close_score);
     sc[p] = s;
     if ((double)s > 1e-6) {
       const int slot = atomicAdd(&s_nlist, 1);
@@ -894,26 +937,32 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
                                 : (size_t)hs * ws * 4 + (size_t)(rows_per_split + 2) * sizeof(TapsP) +
                           ((size_t)(rows_per_split + 3) + (size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4;
   const size_t lds1b = (size_t)hs * ws * 4;
-  const size_t lds2 = (size_t)PAF_LIST_CAP * 8 + ((size_t)2 * hs * ws + (size_t)2 * (m.max_peaks + 1) * 3) * 4 +
-                      (size_t)(Wt + Ht + 1) * sizeof(TapsP) + (size_t)3 * (m.max_peaks + 1) * 8 +
-                      2 * (m.max_peaks + 1) + 32;
+  // PAF planes in LDS as cubic coefficient tables (16 B per source pixel and channel) when they fit, else raw
+  // (POSEHIP_PAF_RAW=1 forces the raw form for A/B runs)
+  static const bool paf_raw = [] { const char* e = getenv("POSEHIP_PAF_RAW"); return e && atoi(e) != 0; }();
+  const size_t lds2_rest = (size_t)PAF_LIST_CAP * 8 + (size_t)2 * (m.max_peaks + 1) * 3 * 4 +
+                           (size_t)(Wt + Ht + 1) * sizeof(TapsP) + (size_t)3 * (m.max_peaks + 1) * 8 +
+                           2 * (m.max_peaks + 1) + 32;
+  const size_t lim = 160 * 1024 - 1024;
+  const bool paf_coef = !paf_raw && lds2_rest + (size_t)2 * hs * ws * 16 <= lim;
+  const size_t lds2 = lds2_rest + (size_t)2 * hs * ws * (paf_coef ? 16 : 4);
   const int row_cap = 2048;
   const size_t lds3 = ((size_t)row_cap + 2 * (size_t)m.n_parts * (m.max_peaks + 1) + 3 * (size_t)m.max_peaks) * 4 +
                       (size_t)2 * (m.max_peaks + 2) * 2 + (size_t)row_cap * (m.n_parts + 1) * 2;
-  const size_t lim = 160 * 1024 - 1024;
   if (lds1 > lim || lds1b > lim || lds2 > lim || lds3 > lim || hs > 65535 || ws > 65535) {
     ph_set_error("decode_v2: LDS budget exceeded (%zu/%zu/%zu B) for net output %dx%d target %dx%d", lds1, lds2,
                  lds3, hs, ws, Ht, Wt);
     return -1;
   }
   static int attr[4][PH_MAX_DEVICES];
-  static int attr_c[3][PH_MAX_DEVICES];
+  static int attr_c[4][PH_MAX_DEVICES];
   if (ph_ensure_lds((const void*)nms_detect_kernel, (int)lim, attr[0]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<1>, (int)lim, attr_c[0]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<2>, (int)lim, attr_c[1]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<4>, (int)lim, attr_c[2]) ||
       ph_ensure_lds((const void*)nms_refine_kernel, (int)lim, attr[1]) ||
-      ph_ensure_lds((const void*)paf_match_kernel, (int)lim, attr[2]) ||
+      ph_ensure_lds((const void*)paf_match_kernel<false>, (int)lim, attr[2]) ||
+      ph_ensure_lds((const void*)paf_match_kernel<true>, (int)lim, attr_c[3]) ||
       ph_ensure_lds((const void*)assemble_kernel, (int)lim, attr[3]))
     return -1;
   PhV2Sizes sz;
@@ -934,8 +983,9 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   hipLaunchKernelGGL(nms_refine_kernel, dim3(m.n_parts, B), dim3(128), lds1b, stream, net_out, C, hs, ws, Ht, Wt,
                      m.max_peaks, m.n_parts, n_split, (const int*)w.nms_keys, (const int*)w.nms_cnt, w.peaks);
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
-  hipLaunchKernelGGL(paf_match_kernel, dim3(m.n_pairs, B), dim3(PAF_THREADS), lds2, stream, net_out, C, hs, ws, Ht, Wt,
-                     (const float*)w.peaks, m, w.pair_scores, w.conn_idx, w.conn_score, w.n_conn);
+  hipLaunchKernelGGL(paf_coef ? paf_match_kernel<true> : paf_match_kernel<false>, dim3(m.n_pairs, B), dim3(PAF_THREADS),
+                     lds2, stream, net_out, C, hs, ws, Ht, Wt, (const float*)w.peaks, m, w.pair_scores, w.conn_idx,
+                     w.conn_score, w.n_conn);
   if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
   hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(64), lds3, stream, (const float*)w.peaks, m,
                      (const int*)w.conn_idx, (const float*)w.conn_score, (const int*)w.n_conn, scale, max_people,
