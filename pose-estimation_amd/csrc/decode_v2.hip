@@ -348,12 +348,11 @@ __global__ __launch_bounds__(128) void nms_refine_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// kernel 2: PAF line-integral scoring + sorted-greedy matching per limb
-// grid (n_pairs, B), block 256
+// kernel 2: PAF line-integral scoring (2a) + sorted-greedy matching per limb (2b)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int pir(float x) { return (int)(x + 0.5f); }
 
-#define PAF_LIST_CAP 2048
+#define PAF_LIST_CAP 8192
 #define PAF_THREADS 1024
 
 // One cubic_row() from a table of its coefficients: cubic()'s a, b, c and v1 depend on the source row and the
@@ -430,12 +429,15 @@ __device__ float score_ab(const float* A, const float* Bp, const void* mapx, con
   return 0.f;
 }
 
+// kernel 2a: scores of the candidate pairs of one limb of one frame; grid (n_pairs, B, n_sub): the pairs of a limb
+// are cut into n_sub ranges (a limb with many accepted pairs costs 10x the average one, and one block per limb
+// left the kernel waiting for its slowest blocks).  Writes the nA x nB score matrix.
+#define PAF_MIN_CHUNK 1024
 template <bool COEF>
-__global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
-                                                        int Ht, int Wt, const float* __restrict__ peaks,
-                                                        PhV2Dev mdl, float* __restrict__ pair_scores,
-                                                        int* __restrict__ conn_idx, float* __restrict__ conn_score,
-                                                        int* __restrict__ n_conn) {
+__global__ __launch_bounds__(PAF_THREADS) void paf_score_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
+                                                                int Ht, int Wt, const float* __restrict__ peaks,
+                                                                PhV2Dev mdl, float* __restrict__ pair_scores,
+                                                                int n_sub) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int pair = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int P1 = mdl.max_peaks + 1;
@@ -443,26 +445,20 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __r
   const float* candA = peaks + ((size_t)b * mdl.n_parts + partA) * P1 * 3;
   const float* candB = peaks + ((size_t)b * mdl.n_parts + partB) * P1 * 3;
   const int nA = pir(candA[0]), nB = pir(candB[0]);
-  int* out_n = n_conn + (size_t)b * mdl.n_pairs + pair;
-  if (nA == 0 || nB == 0) {
-    if (tid == 0) *out_n = 0;
-    return;
-  }
-  constexpr int PLANE_WORDS = COEF ? 4 : 1;                // floats per source pixel and channel
-  unsigned long long* s_list = (unsigned long long*)smem;  // PAF_LIST_CAP accepted (score, i, j) keys
-  float* s_mx = (float*)(s_list + PAF_LIST_CAP);           // (16-byte aligned: PAF_LIST_CAP * 8 bytes in)
+  const int npairs = nA * nB;
+  int chunk = (npairs + n_sub - 1) / n_sub;
+  chunk = chunk < PAF_MIN_CHUNK ? PAF_MIN_CHUNK : chunk;
+  const int p_begin = blockIdx.z * chunk;
+  if (p_begin >= npairs) return;  // (also nA == 0 or nB == 0)
+  const int p_end = p_begin + chunk < npairs ? p_begin + chunk : npairs;
+
+  constexpr int PLANE_WORDS = COEF ? 4 : 1;  // floats per source pixel and channel
+  float* s_mx = smem;
   float* s_my = s_mx + hs * ws * PLANE_WORDS;
   float* s_A = s_my + hs * ws * PLANE_WORDS;  // P1*3
   float* s_B = s_A + P1 * 3;
   TapsP* s_xt = (TapsP*)(s_B + P1 * 3);  // Wt
   TapsP* s_yt = s_xt + Wt;               // Ht
-  unsigned long long* s_bestA = (unsigned long long*)(s_yt + Ht + ((Wt + Ht) & 1));  // keep 8-byte alignment
-  unsigned long long* s_bestB = s_bestA + P1;
-  unsigned long long* s_sel = s_bestB + P1;  // selected keys, <= min(nA, nB) <= max_peaks
-  unsigned char* s_occA = (unsigned char*)(s_sel + P1);
-  unsigned char* s_occB = s_occA + P1;
-  __shared__ unsigned long long s_best;
-  __shared__ int s_count, s_nlist;
   __shared__ unsigned char s_kmin[32];
 
   const float* px = net_out + ((size_t)b * C + mdl.n_heat + mdl.mapidx[2 * pair]) * hs * ws;
@@ -481,10 +477,6 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __r
     s_A[i] = candA[i];
     s_B[i] = candB[i];
   }
-  for (int i = tid; i < P1; i += PAF_THREADS) {
-    s_occA[i] = 0;
-    s_occB[i] = 0;
-  }
   for (int x = tid; x < Wt; x += PAF_THREADS) s_xt[x] = pack_taps(src_taps(x, Wt, ws));
   for (int y = tid; y < Ht; y += PAF_THREADS) s_yt[y] = pack_taps(src_taps(y, Ht, hs));
   if (tid < 32) {  // sample counts are 5..25
@@ -492,27 +484,63 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __r
     while (k <= tid && !((float)k / (float)tid > mdl.inter_min_above)) k++;
     s_kmin[tid] = (unsigned char)k;
   }
+  __syncthreads();
+
+  float* sc = pair_scores + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * mdl.max_peaks;
+  for (int p = p_begin + tid; p < p_end; p += PAF_THREADS) {
+    const int i = p / nB, j = p - i * nB;  // 0-based
+    sc[p] = score_ab<COEF>(s_A + (i + 1) * 3, s_B + (j + 1) * 3, s_mx, s_my, ws, Ht, Wt, s_xt, s_yt,
+                           mdl.inter_threshold, s_kmin, mdl.close_thr, mdl.close_score);
+  }
+}
+
+// kernel 2b: sorted-greedy matching of one limb of one frame from its score matrix; grid (n_pairs, B)
+__global__ __launch_bounds__(PAF_THREADS) void paf_greedy_kernel(const float* __restrict__ peaks, PhV2Dev mdl,
+                                                                 const float* __restrict__ pair_scores,
+                                                                 int* __restrict__ conn_idx,
+                                                                 float* __restrict__ conn_score,
+                                                                 int* __restrict__ n_conn) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int pair = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int P1 = mdl.max_peaks + 1;
+  const int partA = mdl.pairs[2 * pair], partB = mdl.pairs[2 * pair + 1];
+  const int nA = pir(peaks[((size_t)b * mdl.n_parts + partA) * P1 * 3]);
+  const int nB = pir(peaks[((size_t)b * mdl.n_parts + partB) * P1 * 3]);
+  int* out_n = n_conn + (size_t)b * mdl.n_pairs + pair;
+  if (nA == 0 || nB == 0) {
+    if (tid == 0) *out_n = 0;
+    return;
+  }
+  unsigned long long* s_list = (unsigned long long*)smem;  // PAF_LIST_CAP accepted (score, i, j) keys
+  unsigned long long* s_bestA = s_list + PAF_LIST_CAP;
+  unsigned long long* s_bestB = s_bestA + P1;
+  unsigned long long* s_sel = s_bestB + P1;  // selected keys, <= min(nA, nB) <= max_peaks
+  unsigned char* s_occA = (unsigned char*)(s_sel + P1);
+  unsigned char* s_occB = s_occA + P1;
+  __shared__ unsigned long long s_best;
+  __shared__ int s_count, s_nlist;
+  for (int i = tid; i < P1; i += PAF_THREADS) {
+    s_occA[i] = 0;
+    s_occB[i] = 0;
+  }
   if (tid == 0) {
     s_best = 0ull;
     s_count = 0;
     s_nlist = 0;
   }
   __syncthreads();
-
-  float* sc = pair_scores + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * mdl.max_peaks;
+  const float* sc = pair_scores + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * mdl.max_peaks;
   const int npairs = nA * nB;
   for (int p = tid; p < npairs; p += PAF_THREADS) {
-    const int i = p / nB, j = p - i * nB;  // 0-based
-    const float s = score_ab<COEF>(s_A + (i + 1) * 3, s_B + (j + 1) * 3, s_mx, s_my, ws, Ht, Wt, s_xt, s_yt,
-                                   mdl.inter_threshold, s_kmin, mdl.close_thr, mdl.close_score);
-    sc[p] = s;
+    const float s = sc[p];
     if ((double)s > 1e-6) {
+      const int i = p / nB, j = p - i * nB;
       const int slot = atomicAdd(&s_nlist, 1);
       if (slot < PAF_LIST_CAP)
         s_list[slot] = ((unsigned long long)__float_as_uint(s) << 32) | ((unsigned)(i + 1) << 16) | (unsigned)(j + 1);
     }
   }
-  __syncthreads();  // list complete; this block's own global writes are visible to it
+  __syncthreads();
 
   // Sorted-greedy matching, in parallel.  Upstream sorts all accepted (score, i, j)
   // descending and takes a pair when both ends are unused.  A pair that is the largest
@@ -521,7 +549,7 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_match_kernel(const float* __r
   // free.  The selected set equals the sequential result; it is emitted in descending
   // key order = the order upstream appends connections.
   const int nlist = s_nlist;
-  const bool use_list = nlist <= PAF_LIST_CAP;
+  const bool use_list = nlist <= PAF_LIST_CAP;  // else the rounds re-read the score matrix
   int* oi = conn_idx + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * 2;
   float* os = conn_score + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks;
   const int off = 3 * P1;
@@ -940,29 +968,32 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   // PAF planes in LDS as cubic coefficient tables (16 B per source pixel and channel) when they fit, else raw
   // (POSEHIP_PAF_RAW=1 forces the raw form for A/B runs)
   static const bool paf_raw = [] { const char* e = getenv("POSEHIP_PAF_RAW"); return e && atoi(e) != 0; }();
-  const size_t lds2_rest = (size_t)PAF_LIST_CAP * 8 + (size_t)2 * (m.max_peaks + 1) * 3 * 4 +
-                           (size_t)(Wt + Ht + 1) * sizeof(TapsP) + (size_t)3 * (m.max_peaks + 1) * 8 +
-                           2 * (m.max_peaks + 1) + 32;
+  const size_t lds2_rest = (size_t)2 * (m.max_peaks + 1) * 3 * 4 + (size_t)(Wt + Ht + 1) * sizeof(TapsP) + 64;
+  const size_t lds2g = (size_t)PAF_LIST_CAP * 8 + (size_t)3 * (m.max_peaks + 1) * 8 + 2 * (m.max_peaks + 1) + 32;
+  // ranges per limb in the scoring kernel: enough blocks to level a few heavy limbs out over the chip
+  int paf_sub = 4096 / (m.n_pairs * B > 0 ? m.n_pairs * B : 1);
+  paf_sub = paf_sub < 1 ? 1 : (paf_sub > 8 ? 8 : paf_sub);
   const size_t lim = 160 * 1024 - 1024;
   const bool paf_coef = !paf_raw && lds2_rest + (size_t)2 * hs * ws * 16 <= lim;
   const size_t lds2 = lds2_rest + (size_t)2 * hs * ws * (paf_coef ? 16 : 4);
   const int row_cap = 2048;
   const size_t lds3 = ((size_t)row_cap + 2 * (size_t)m.n_parts * (m.max_peaks + 1) + 3 * (size_t)m.max_peaks) * 4 +
                       (size_t)2 * (m.max_peaks + 2) * 2 + (size_t)row_cap * (m.n_parts + 1) * 2;
-  if (lds1 > lim || lds1b > lim || lds2 > lim || lds3 > lim || hs > 65535 || ws > 65535) {
+  if (lds1 > lim || lds1b > lim || lds2 > lim || lds2g > lim || lds3 > lim || hs > 65535 || ws > 65535) {
     ph_set_error("decode_v2: LDS budget exceeded (%zu/%zu/%zu B) for net output %dx%d target %dx%d", lds1, lds2,
                  lds3, hs, ws, Ht, Wt);
     return -1;
   }
   static int attr[4][PH_MAX_DEVICES];
-  static int attr_c[4][PH_MAX_DEVICES];
+  static int attr_c[5][PH_MAX_DEVICES];
   if (ph_ensure_lds((const void*)nms_detect_kernel, (int)lim, attr[0]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<1>, (int)lim, attr_c[0]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<2>, (int)lim, attr_c[1]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<4>, (int)lim, attr_c[2]) ||
       ph_ensure_lds((const void*)nms_refine_kernel, (int)lim, attr[1]) ||
-      ph_ensure_lds((const void*)paf_match_kernel<false>, (int)lim, attr[2]) ||
-      ph_ensure_lds((const void*)paf_match_kernel<true>, (int)lim, attr_c[3]) ||
+      ph_ensure_lds((const void*)paf_score_kernel<false>, (int)lim, attr[2]) ||
+      ph_ensure_lds((const void*)paf_score_kernel<true>, (int)lim, attr_c[3]) ||
+      ph_ensure_lds((const void*)paf_greedy_kernel, (int)lim, attr_c[4]) ||
       ph_ensure_lds((const void*)assemble_kernel, (int)lim, attr[3]))
     return -1;
   PhV2Sizes sz;
@@ -983,9 +1014,11 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   hipLaunchKernelGGL(nms_refine_kernel, dim3(m.n_parts, B), dim3(128), lds1b, stream, net_out, C, hs, ws, Ht, Wt,
                      m.max_peaks, m.n_parts, n_split, (const int*)w.nms_keys, (const int*)w.nms_cnt, w.peaks);
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
-  hipLaunchKernelGGL(paf_coef ? paf_match_kernel<true> : paf_match_kernel<false>, dim3(m.n_pairs, B), dim3(PAF_THREADS),
-                     lds2, stream, net_out, C, hs, ws, Ht, Wt, (const float*)w.peaks, m, w.pair_scores, w.conn_idx,
-                     w.conn_score, w.n_conn);
+  hipLaunchKernelGGL(paf_coef ? paf_score_kernel<true> : paf_score_kernel<false>, dim3(m.n_pairs, B, paf_sub),
+                     dim3(PAF_THREADS), lds2, stream, net_out, C, hs, ws, Ht, Wt, (const float*)w.peaks, m,
+                     w.pair_scores, paf_sub);
+  hipLaunchKernelGGL(paf_greedy_kernel, dim3(m.n_pairs, B), dim3(PAF_THREADS), lds2g, stream, (const float*)w.peaks, m,
+                     (const float*)w.pair_scores, w.conn_idx, w.conn_score, w.n_conn);
   if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
   hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(64), lds3, stream, (const float*)w.peaks, m,
                      (const int*)w.conn_idx, (const float*)w.conn_score, (const int*)w.n_conn, scale, max_people,
