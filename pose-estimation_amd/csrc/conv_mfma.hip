@@ -30,6 +30,10 @@ __device__ unsigned long long ph_conv_dbg[8];
 // Diagnostic build only (tools/conv_timeline.py): per block of the last branch-free 3x3 launch, the 100 MHz
 // s_memrealtime at kernel entry, K loop start, K loop end and after the last store has been issued, + the CU id.
 __device__ unsigned long long ph_conv_tl[4096 * 5];
+__device__ unsigned long long ph_conv_tlw[1024 * 8 * 8];   // per wave of the first 1024 blocks: epilogue stamps
+extern "C" int ph_debug_conv_timeline_waves(unsigned long long* out, int nblocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ph_conv_tlw), (size_t)nblocks * 64 * sizeof(unsigned long long));
+}
 extern "C" int ph_debug_conv_timeline(unsigned long long* out, int nblocks) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ph_conv_tl), (size_t)nblocks * 5 * sizeof(unsigned long long));
 }
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #endif
 #ifdef PH_TIMELINE
   const unsigned long long tl0_ = __builtin_amdgcn_s_memrealtime();
-  unsigned long long tl1_ = 0, tl2_ = 0;
+  unsigned long long tl1_ = 0, tl2_ = 0, tw_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
   const unsigned nblk = gridDim.x;
@@ -688,9 +692,13 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #endif
       }
     }
+#ifdef PH_TIMELINE
+    tw_[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetches past the end of K
 #ifdef PH_TIMELINE
     tl2_ = __builtin_amdgcn_s_memrealtime();
+    tw_[1] = tl2_;
 #endif
 #ifdef PH_LIN_STAMP
     if (lane == 0 && wave == 1 && !p.debug_epi) {
@@ -831,7 +839,13 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #ifdef PH_LIN_STAMP
   const long long e1_ = __builtin_readcyclecounter();
 #endif
+#ifdef PH_TIMELINE
+  tw_[2] = __builtin_amdgcn_s_memrealtime();
+#endif
   __syncthreads();  // all fragment reads done, no LDS-DMA in flight (the last step waited for vmcnt(0))
+#ifdef PH_TIMELINE
+  tw_[3] = __builtin_amdgcn_s_memrealtime();
+#endif
   // per output row: {batch index or -1, y << 16 | x} (interior coordinates)
   int2* s_row = (int2*)(lds + HALO_BM * CROWB);  // behind the staged output tile (which may cover every other region)
   if (tid >= HALO_BM) {
@@ -878,6 +892,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   const long long e2_ = __builtin_readcyclecounter();
   long long e3_ = e2_;
 #endif
+#ifdef PH_TIMELINE
+  tw_[4] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (p.n_dst > 0) {
     // the whole 256 x BN tile goes through LDS at once (bias/slope and the K-loop buffers are dead by now)
 #pragma unroll
@@ -892,6 +909,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     __syncthreads();
 #ifdef PH_LIN_STAMP
     e3_ = __builtin_readcyclecounter();
+#endif
+#ifdef PH_TIMELINE
+    tw_[5] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (p.pool) {
       // 2x2/2 max pool of the 16x16 tile -> 8 x 8 pooled pixels
@@ -969,6 +989,12 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     unsigned long long* o = ph_conv_tl + blockIdx.x * 5;
     o[0] = tl0_; o[1] = tl1_; o[2] = tl2_; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = hwid;
+  }
+  if (LINC && LIN && lane == 0 && blockIdx.x < 1024) {
+    tw_[6] = __builtin_amdgcn_s_memrealtime();
+    tw_[7] = tl0_;
+    unsigned long long* o = ph_conv_tlw + (blockIdx.x * 8 + wave) * 8;
+    for (int k = 0; k < 8; k++) o[k] = tw_[k];
   }
 #endif
   if (dbg_t) {

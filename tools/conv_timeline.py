@@ -62,3 +62,20 @@ u, inv2, cnt = np.unique(key, return_inverse=True, return_counts=True)
 print("blocks per (XCD, CU) histogram:", np.bincount(cnt).tolist())
 alone = cnt[inv2] == 1
 print("K loop median us: alone on a CU", round(float(np.median(kl[alone])), 1) if alone.any() else None, " sharing", round(float(np.median(kl[~alone])), 1))
+# per-wave epilogue stamps (first min(nblk, 1024) blocks)
+nb = min(nblk, 1024)
+bw = (ctypes.c_ulonglong * (nb * 64))()
+if hasattr(L, "ph_debug_conv_timeline_waves") and L.ph_debug_conv_timeline_waves(bw, nb) == 0:
+    w = np.array(bw, dtype=np.int64).reshape(nb, 8, 8).astype(np.float64)
+    t0 = w[:, :, 7].min(axis=1)[:, None, None]
+    w = (w - t0) / 100.0
+    names = ["last step done", "re-fetches landed", "bias+act done", "barrier passed", "row table done", "staged", "stores issued"]
+    print("per-wave epilogue stamps, us from block entry (median over blocks; per wave 0..7):")
+    for k, nme in enumerate(names):
+        print(f"  {nme:18s}", [round(float(np.median(w[:, wv, k])), 2) for wv in range(8)])
+    print("  barrier wait per wave (us, median):", [round(float(np.median(w[:, wv, 3] - w[:, wv, 2])), 2) for wv in range(8)])
+    sl = kl[:nb] > (kl.min() + kl.max()) / 2
+    for nme, sel in (("fast blocks", ~sl), ("slow blocks", sl)):
+        if sel.any():
+            print(f"  {nme}: last step done -> stores issued (us, median over waves & blocks)",
+                  [round(float(np.median(w[sel][:, :, k])), 2) for k in range(7)])
