@@ -68,6 +68,20 @@ def test_crowded_and_truncation(engine):
         _check_frame(kp_o, sc_o, inter, got, extras, b, BODY_25, engine)
 
 
+@pytest.mark.parametrize("hs,ws", [
+    (12, 130),    # 96 x 1040 target: two column groups per wave in the NMS kernel
+    (14, 260),    # 112 x 2080 target: four column groups per wave
+    (92, 164),    # 736 x 1312 target: PAF planes too large for coefficient tables -> raw planes in LDS
+])
+def test_wide_targets(engine, hs, ws):
+    f = synth.synth_net_output(11, 3, BODY_25, hs, ws)[None]
+    engine.set_net_out(f)
+    got, extras = engine.decode_v2(BODY_25, 1, hs * 8, ws * 8, want_peaks=True, want_subsets=True)
+    kp_o, sc_o, inter = _oracle(f[0], BODY_25, hs * 8, ws * 8, 1.0)
+    _check_frame(kp_o, sc_o, inter, got, extras, 0, BODY_25, engine)
+    assert extras["peaks"][0, :, 0, 0].sum() > 0
+
+
 def test_empty_and_flat_maps(engine):
     z = np.zeros((2, BODY_25.n_channels, 46, 82), np.float32)
     z[1] = 0.5                                   # plateau: strict > never fires
