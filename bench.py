@@ -65,7 +65,8 @@ def main():
     ap.add_argument("--h2d", action="store_true",
                     help="frames start in pinned HOST memory and are copied in every step (PCIe-inclusive "
                          "rate for DESIGN.md; never the headline value)")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=24,
+                    help="frames of the CPU baseline sample (about 12 s of host work on 16 cores; 0 = skip)")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when its first communicator
