@@ -82,6 +82,24 @@ def test_wide_targets(engine, hs, ws):
     assert extras["peaks"][0, :, 0, 0].sum() > 0
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_sizes_and_ratios(engine, seed):
+    # non-integer upsampling ratios (runs of rows with equal vertical taps of uneven length), odd sizes, stripes that
+    # end inside a band, widths around the 62-column groups of the NMS kernel
+    rng = np.random.default_rng(900 + seed)
+    hs, ws = int(rng.integers(14, 40)), int(rng.integers(14, 60))
+    Ht = int(hs * rng.uniform(4.0, 9.0)) + int(rng.integers(0, 3))
+    Wt = int(ws * rng.uniform(4.0, 9.0)) + int(rng.integers(0, 3))
+    Ht, Wt = max(Ht, 4 * hs), max(Wt, 4 * ws)
+    f = np.stack([synth.synth_net_output(50 + seed, 2, BODY_25, hs, ws),
+                  synth.synth_net_output(70 + seed, 4, BODY_25, hs, ws)])
+    engine.set_net_out(f)
+    got, extras = engine.decode_v2(BODY_25, 2, Ht, Wt, scale=1.25, want_peaks=True, want_subsets=True)
+    for b in range(2):
+        kp_o, sc_o, inter = _oracle(f[b], BODY_25, Ht, Wt, 1.25)
+        _check_frame(kp_o, sc_o, inter, got, extras, b, BODY_25, engine)
+
+
 def test_empty_and_flat_maps(engine):
     z = np.zeros((2, BODY_25.n_channels, 46, 82), np.float32)
     z[1] = 0.5                                   # plateau: strict > never fires
