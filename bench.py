@@ -159,6 +159,8 @@ def main():
         k = i % S
         e, ts, d = engs[k], tstreams[k], bufs[k]
         ts.synchronize()           # the batch this engine ran S steps ago has delivered its keypoints
+        if i >= S and not os.environ.get("BENCH_DIAG_NO_DECODE"):
+            e.decode_v2_status()   # raises if that batch's decode dropped people (person table overflow)
         if args.h2d:
             with torch.cuda.stream(ts):
                 d["frames"].copy_(frames_host, non_blocking=True)

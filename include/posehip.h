@@ -158,8 +158,14 @@ int ph_decode_v2_dev(ph_ctx* ctx, const ph_v2_model* model, int B, int Ht, int W
 /* asynchronous copy (on the ctx stream, no wait) of the last ph_decode_v2_dev
  * results into caller buffers of the shapes above: pinned host memory
  * (dst_on_device=0) or device memory (dst_on_device=1, e.g. the send buffer of
- * the RCCL keypoint gather).  Any pointer may be NULL. */
+ * the RCCL keypoint gather).  Any pointer may be NULL.  The decode's overflow flag is copied along (to pinned
+ * memory of the ctx): call ph_decode_v2_status() after the stream has been synchronised. */
 int ph_decode_v2_results(ph_ctx* ctx, int32_t* n_people, float* keypoints, float* scores, int dst_on_device);
+/* Overflow report of the asynchronous path: waits for the ctx stream, then returns -2 (and sets the error) when the
+ * decode whose results the last ph_decode_v2_results call copied had more than 2048 partial skeletons in a frame
+ * (people were dropped), 0 otherwise.  ph_decode_v2 reports the same condition through its own return value. */
+int ph_decode_v2_status(ph_ctx* ctx);
+
 /* Per-person post-processing of the LAST ph_decode_v2(_dev) results, on the device keypoints (no D2H first):
  *  bbox  [B][max_people][4] f32 (u_min, v_min, u_max, v_max) over the `torso_ids` joints with score != 0
  *        (degenerate side -> +1, none -> 0,0,1,1): PyOpenPoseNativeBase.pose_bounding_box,

@@ -98,6 +98,7 @@ struct ph_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev1[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> op_ev;
+  int* overflow_host = nullptr;  // pinned: V2 overflow flag of the last ph_decode_v2_results
   // ph_pose_post scratch (grown on demand)
   void* post = nullptr;
   size_t post_bytes = 0;
@@ -121,6 +122,20 @@ int ph_device_ok(int device) {
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
+static int create_resources(ph_ctx* c, void* stream) {
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    PH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  for (int i = 0; i < 4; i++) PH_CHECK(hipEventCreate(&c->ev[i]));
+  for (int i = 0; i < 4; i++) PH_CHECK(hipEventCreate(&c->ev1[i]));
+  PH_CHECK(hipHostMalloc((void**)&c->overflow_host, sizeof(int), hipHostMallocDefault));
+  *c->overflow_host = 0;
+  return 0;
+}
+
 int ph_create(ph_ctx** out, int device, void* stream) {
   if (!out) {
     ph_set_error("ph_create: null out");
@@ -141,14 +156,11 @@ int ph_create(ph_ctx** out, int device, void* stream) {
   }
   ph_ctx* c = new ph_ctx();
   c->device = device;
-  if (stream) {
-    c->stream = (hipStream_t)stream;
-  } else {
-    PH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
+  const int rc = create_resources(c, stream);
+  if (rc) {  // ph_destroy releases whatever was created before the failure
+    ph_destroy(c);
+    return rc;
   }
-  for (int i = 0; i < 4; i++) PH_CHECK(hipEventCreate(&c->ev[i]));
-  for (int i = 0; i < 4; i++) PH_CHECK(hipEventCreate(&c->ev1[i]));
   *out = c;
   return 0;
 }
@@ -198,6 +210,7 @@ void ph_destroy(ph_ctx* c) {
   if (c->inj_out) (void)hipFree(c->inj_out);
   if (c->frames) (void)hipFree(c->frames);
   if (c->post) (void)hipFree(c->post);
+  if (c->overflow_host) (void)hipHostFree(c->overflow_host);
   for (int i = 0; i < 4; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -704,23 +717,13 @@ int ph_argmax_maps(ph_ctx* c, int B, float* vals_host, int32_t* locs_host) {
 }
 
 // ---- V2 decode ---------------------------------------------------------------
-static int v2_prepare(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, int max_people, PhV2Dev* dev) {
-  PH_CHECK(hipSetDevice(c->device));
-  if (!m || B < 1 || max_people < 1 || !c->cur_out) {
-    ph_set_error("ph_decode_v2: bad args or no net output");
-    return -1;
-  }
-  if ((size_t)B * c->cur_c * c->cur_h * c->cur_w > c->cur_elems) {
-    ph_set_error("ph_decode_v2: batch %d exceeds the resident net output", B);
-    return -1;
-  }
+static int v2_model_to_dev(const ph_v2_model* m, int C, int Ht, int Wt, PhV2Dev* dev) {
   if (m->n_pairs > 64 || m->n_pairs < 1 || m->n_parts < 1 || m->max_peaks < 1 || m->max_peaks > 1023) {
     ph_set_error("ph_decode_v2: bad model constants");
     return -1;
   }
   for (int k = 0; k < 2 * m->n_pairs; k++)
-    if (m->pairs[k] < 0 || m->pairs[k] >= m->n_parts || m->mapidx[k] < 0 ||
-        m->n_heat + m->mapidx[k] >= c->cur_c) {
+    if (m->pairs[k] < 0 || m->pairs[k] >= m->n_parts || m->mapidx[k] < 0 || m->n_heat + m->mapidx[k] >= C) {
       ph_set_error("ph_decode_v2: pair/mapidx table entry %d out of range", k);
       return -1;
     }
@@ -740,6 +743,20 @@ static int v2_prepare(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, in
   dev->close_thr = sqrt((double)(Wt * Ht)) / 150.0;
   memcpy(dev->pairs, m->pairs, sizeof(int) * 2 * m->n_pairs);
   memcpy(dev->mapidx, m->mapidx, sizeof(int) * 2 * m->n_pairs);
+  return 0;
+}
+
+static int v2_prepare(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, int max_people, PhV2Dev* dev) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!m || B < 1 || max_people < 1 || !c->cur_out) {
+    ph_set_error("ph_decode_v2: bad args or no net output");
+    return -1;
+  }
+  if ((size_t)B * c->cur_c * c->cur_h * c->cur_w > c->cur_elems) {
+    ph_set_error("ph_decode_v2: batch %d exceeds the resident net output", B);
+    return -1;
+  }
+  if (v2_model_to_dev(m, c->cur_c, Ht, Wt, dev)) return -1;
   const size_t key = ((size_t)B << 40) ^ ((size_t)max_people << 24) ^ ((size_t)m->n_parts << 16) ^
                      ((size_t)m->n_pairs << 8) ^ (size_t)m->max_peaks;
   if (key != c->v2_key) {
@@ -789,7 +806,8 @@ int ph_decode_v2(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, float s
   PH_CHECK(hipMemcpyAsync(&overflow, c->v2.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
   PH_CHECK(hipStreamSynchronize(s));
   if (overflow) {
-    ph_set_error("ph_decode_v2: person-candidate table overflowed (more than 2048 partial skeletons in a frame)");
+    ph_set_error("ph_decode_v2: person-candidate table overflowed (more than %d partial skeletons in a frame)",
+                 PH_V2_ROW_CAP);
     return -2;
   }
   return 0;
@@ -806,6 +824,23 @@ int ph_decode_v2_results(ph_ctx* c, int32_t* n_people, float* keypoints, float* 
   if (n_people) PH_CHECK(hipMemcpyAsync(n_people, c->v2.n_people, c->v2sz.n_people, k, s));
   if (keypoints) PH_CHECK(hipMemcpyAsync(keypoints, c->v2.keypoints, c->v2sz.keypoints, k, s));
   if (scores) PH_CHECK(hipMemcpyAsync(scores, c->v2.scores, c->v2sz.scores, k, s));
+  // the overflow flag travels with the results; ph_decode_v2_status() reads it once the stream has drained
+  PH_CHECK(hipMemcpyAsync(c->overflow_host, c->v2.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+int ph_decode_v2_status(ph_ctx* c) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!c->v2.n_people || !c->overflow_host) {
+    ph_set_error("ph_decode_v2_status: no decode has run");
+    return -1;
+  }
+  PH_CHECK(hipStreamSynchronize(c->stream));
+  if (*c->overflow_host) {
+    ph_set_error("ph_decode_v2: person-candidate table overflowed (more than %d partial skeletons in a frame)",
+                 PH_V2_ROW_CAP);
+    return -2;
+  }
   return 0;
 }
 

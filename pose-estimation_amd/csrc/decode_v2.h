@@ -13,6 +13,7 @@ struct PhV2Dev {
   int mapidx[128];
 };
 
+#define PH_V2_ROW_CAP 2048  // partial skeletons per frame the assembly kernel holds in LDS
 #define PH_V2_NMS_SPLIT 4  // horizontal stripes per heat map in the NMS kernel
 
 struct PhV2Sizes {

@@ -976,7 +976,7 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   const size_t lim = 160 * 1024 - 1024;
   const bool paf_coef = !paf_raw && lds2_rest + (size_t)2 * hs * ws * 16 <= lim;
   const size_t lds2 = lds2_rest + (size_t)2 * hs * ws * (paf_coef ? 16 : 4);
-  const int row_cap = 2048;
+  const int row_cap = PH_V2_ROW_CAP;
   const size_t lds3 = ((size_t)row_cap + 2 * (size_t)m.n_parts * (m.max_peaks + 1) + 3 * (size_t)m.max_peaks) * 4 +
                       (size_t)2 * (m.max_peaks + 2) * 2 + (size_t)row_cap * (m.n_parts + 1) * 2;
   if (lds1 > lim || lds1b > lim || lds2 > lim || lds2g > lim || lds3 > lim || hs > 65535 || ws > 65535) {

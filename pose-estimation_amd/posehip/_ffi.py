@@ -93,6 +93,7 @@ SYMBOLS = {
                                    C.POINTER(_vp), C.POINTER(_vp),
                                    C.POINTER(_vp)]),
     "ph_decode_v2_results": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "ph_decode_v2_status": (C.c_int, [_vp]),
     "ph_decode_v2_connections": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ph_decode_v1": (C.c_int, [_vp, C.POINTER(PhV1Model), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                _vp, _vp, _vp, _vp, _vp, _vp]),

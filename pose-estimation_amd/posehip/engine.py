@@ -183,6 +183,11 @@ class Engine:
                                                   C.c_void_p(keypoints.data_ptr()), C.c_void_p(scores.data_ptr()),
                                                   on_dev), "ph_decode_v2_results")
 
+    def decode_v2_status(self):
+        """Waits for the stream; raises PosehipError (-2) if the decode whose results were last copied by
+        decode_v2_results dropped people (more than 2048 partial skeletons in a frame)."""
+        _ffi.check(self._lib.ph_decode_v2_status(self._ctx), "ph_decode_v2_status")
+
     def pose_post(self, B, max_people, n_parts, torso_ids=None, depth=None, intr=None, depth_scale=1e-3,
                   patch_offset=2):
         """Torso boxes and / or 3-D lift of the last decode_v2(_dev) results, computed on the device keypoints.

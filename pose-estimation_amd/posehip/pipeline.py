@@ -43,9 +43,10 @@ class BatchPipeline:
             return
         self.streams[k].synchronize()
         ticket, B = self._pending[k]
+        self._pending[k] = None
+        self.engines[k].decode_v2_status()    # raises (-2) if this batch's decode dropped people
         n, kp, sc = self.out[k]
         self._done[ticket] = (n[:B].numpy().copy(), kp[:B].numpy().copy(), sc[:B].numpy().copy())
-        self._pending[k] = None
 
     def submit(self, frames):
         """frames: contiguous CUDA u8 tensor [B<=batch, H0, W0, 3] BGR (must stay alive until `result`).

@@ -230,3 +230,35 @@ def test_pose_features_degenerate_crop_flags_index_error(engine):
     feat, status = engine.pose_features(1, 128, BODY_25.n_parts, TORSO_IDS, [(0, 25)], BODY_25.n_heat, 1, hs * 8, ws * 8,
                                         (656 * 4000, 368), n)
     assert (status == -1).all() and not feat.any()
+
+
+def test_person_table_overflow_is_reported_on_both_paths(engine):
+    """More than 2048 partial skeletons in a frame: ph_decode_v2 returns -2, and so does ph_decode_v2_status after
+    the asynchronous ph_decode_v2_dev + ph_decode_v2_results (the path BatchPipeline and bench.py use)."""
+    import torch
+    from posehip.tables import PoseModelV2
+    # star model: 23 limbs (k, 0) whose B side (part 0) has no peak -> every peak of the 23 other parts becomes a
+    # single-part person: 23 x 127 = 2921 rows (upstream createPeopleVector, the "one side empty" branch)
+    star = PoseModelV2("star", [f"p{i}" for i in range(24)] + ["Background"], [(k, 0) for k in range(1, 24)],
+                       [(2 * k, 2 * k + 1) for k in range(23)], (-1, -1))
+    rng = np.random.default_rng(3)
+    f = np.zeros((1, star.n_channels, 46, 82), np.float32)
+    f[0, 1:24] = rng.uniform(0.1, 1.0, (23, 46, 82)).astype(np.float32)
+    engine.set_net_out(f)
+    with pytest.raises(_ffi.PosehipError, match=r"\(-2\).*overflow"):
+        engine.decode_v2(star, 1, 368, 656, max_people=128)
+    pn, pk, ps = engine.decode_v2_dev(star, 1, 368, 656, max_people=128)
+    n = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    kp = torch.zeros((1, 128, 24, 3), dtype=torch.float32).pin_memory()
+    sc = torch.zeros((1, 128), dtype=torch.float32).pin_memory()
+    engine.decode_v2_results(n, kp, sc)
+    with pytest.raises(_ffi.PosehipError, match=r"\(-2\).*overflow"):
+        engine.decode_v2_status()
+    # a frame that fits clears the flag again
+    ok = synth.synth_net_output(5, 2, BODY_25, 46, 82)[None]
+    engine.set_net_out(ok)
+    engine.decode_v2_dev(BODY_25, 1, 368, 656)
+    kp25 = torch.zeros((1, 128, 25, 3), dtype=torch.float32).pin_memory()
+    engine.decode_v2_results(n, kp25, sc)
+    engine.decode_v2_status()
+    assert int(n[0]) >= 1
