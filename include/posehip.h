@@ -166,6 +166,20 @@ int ph_decode_v2_results(ph_ctx* ctx, int32_t* n_people, float* keypoints, float
  * (people were dropped), 0 otherwise.  ph_decode_v2 reports the same condition through its own return value. */
 int ph_decode_v2_status(ph_ctx* ctx);
 
+/* The one entry point that allocates nothing.  It has NO counterpart in the reference: it exists for callers that
+ * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same kernels and results as ph_decode_v2_dev, but the net output is the caller's device buffer
+ * (f32 [B][C][Hs][Ws]), the results go to the caller's device buffers (shapes as above) and the workspace (peak
+ * tables, PAF score matrices, connection lists) lives in a 16 MiB static device array of the library, one per GPU,
+ * held until the process ends.  Limit: B <= PH_NOALLOC_MAX_FRAMES and the workspace of the B frames must fit the
+ * array (it does for BODY_25 / COCO with 127 peaks per part); larger calls return -3 and launch nothing.  Asynchronous on the ctx stream.
+ * overflow_dev (device int32, may be NULL) receives 1 when a frame had more than 2048 partial skeletons.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two ctxs, two streams) race. */
+#define PH_NOALLOC_MAX_FRAMES 8
+int ph_decode_v2_noalloc(ph_ctx* ctx, const ph_v2_model* model, const float* net_out_dev, int B, int C, int Hs, int Ws,
+                         int Ht, int Wt, float scale, int max_people, int32_t* n_people_dev, float* keypoints_dev,
+                         float* scores_dev, int32_t* overflow_dev);
+
 /* Per-person post-processing of the LAST ph_decode_v2(_dev) results, on the device keypoints (no D2H first):
  *  bbox  [B][max_people][4] f32 (u_min, v_min, u_max, v_max) over the `torso_ids` joints with score != 0
  *        (degenerate side -> +1, none -> 0,0,1,1): PyOpenPoseNativeBase.pose_bounding_box,

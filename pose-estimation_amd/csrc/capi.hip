@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/posehip.h"
@@ -40,6 +41,27 @@ int ph_launch_preprocess(const uint8_t* frames, int B, int H0, int W0, int Hn, i
                          int out_Hp, int out_Wp, int out_Cs, int out_org, hipStream_t stream);
 
 static thread_local char g_err[1024] = "";
+
+// Workspace of ph_decode_v2_noalloc (the one entry point that allocates nothing).  In host code the name `scratch`
+// is only a handle for hipGetSymbolAddress: the device address of each GPU's own copy is looked up once per device
+// in ph_create (that device current) and kept in g_scratch_ptr; host code uses that pointer everywhere.
+#define PH_SCRATCH_BYTES (16u << 20)
+static __device__ __align__(256) unsigned char scratch[PH_SCRATCH_BYTES];
+static void* g_scratch_ptr[PH_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int scratch_init(int device) {
+  if (device < 0 || device >= PH_MAX_DEVICES) {
+    ph_set_error("device %d beyond the %d the library keeps a scratch pointer for", device, PH_MAX_DEVICES);
+    return -1;
+  }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_scratch_ptr[device]) return 0;
+  void* p = nullptr;
+  PH_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));  // the current device's copy
+  g_scratch_ptr[device] = p;
+  return 0;
+}
 
 void ph_set_error(const char* fmt, ...) {
   va_list ap;
@@ -154,6 +176,7 @@ int ph_create(ph_ctx** out, int device, void* stream) {
     ph_set_error("ph_create: device %d is not gfx950 (libposehip is built for MI355X only)", device);
     return -1;
   }
+  if (scratch_init(device)) return -1;
   ph_ctx* c = new ph_ctx();
   c->device = device;
   const int rc = create_resources(c, stream);
@@ -841,6 +864,58 @@ int ph_decode_v2_status(ph_ctx* c) {
                  PH_V2_ROW_CAP);
     return -2;
   }
+  return 0;
+}
+
+// The entry point that allocates nothing: same kernels as ph_decode_v2_dev, workspace carved out of this GPU's
+// copy of `scratch` (through g_scratch_ptr, never the symbol itself), inputs and outputs are the caller's.
+int ph_decode_v2_noalloc(ph_ctx* c, const ph_v2_model* m, const float* net_out_dev, int B, int C, int Hs, int Ws,
+                         int Ht, int Wt, float scale, int max_people, int32_t* n_people_dev, float* keypoints_dev,
+                         float* scores_dev, int32_t* overflow_dev) {
+  PH_CHECK(hipSetDevice(c->device));
+  if (!m || !net_out_dev || !n_people_dev || !keypoints_dev || !scores_dev || B < 1 || C < 1 || Hs < 1 || Ws < 1 ||
+      max_people < 1) {
+    ph_set_error("ph_decode_v2_noalloc: bad arguments");
+    return -1;
+  }
+  unsigned char* base = (unsigned char*)g_scratch_ptr[c->device];
+  if (!base) {
+    ph_set_error("ph_decode_v2_noalloc: no scratch address for device %d", c->device);
+    return -1;
+  }
+  PhV2Dev dev;
+  if (v2_model_to_dev(m, C, Ht, Wt, &dev)) return -1;
+  PhV2Sizes sz;
+  ph_v2_workspace_sizes(dev, B, max_people, &sz);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    unsigned char* p = base + off;
+    off += (bytes + 255) & ~(size_t)255;
+    return p;
+  };
+  PhV2Buffers w = {};
+  w.overflow = (int*)carve(sizeof(int));
+  w.nms_keys = (int*)carve(sz.nms_keys);
+  w.nms_cnt = (int*)carve(sz.nms_cnt);
+  w.peaks = (float*)carve(sz.peaks);
+  w.pair_scores = (float*)carve(sz.pair_scores);
+  w.conn_idx = (int*)carve(sz.conn_idx);
+  w.conn_score = (float*)carve(sz.conn_score);
+  w.n_conn = (int*)carve(sz.n_conn);
+  w.subsets = nullptr;  // optional output of the assembly kernel, not offered here
+  if (B > PH_NOALLOC_MAX_FRAMES || off > PH_SCRATCH_BYTES) {
+    ph_set_error("ph_decode_v2_noalloc: %d frames need %zu B of workspace; the static scratch holds %u B and a call "
+                 "at most %d frames", B, off, PH_SCRATCH_BYTES, PH_NOALLOC_MAX_FRAMES);
+    return -3;
+  }
+  w.n_people = n_people_dev;
+  w.keypoints = keypoints_dev;
+  w.scores = scores_dev;
+  // ph_launch_decode_v2 clears what must start at zero (peak table, overflow flag); every other part of the
+  // workspace is fully rewritten before it is read, so the previous call's contents do not matter
+  if (ph_launch_decode_v2(net_out_dev, C, Hs, Ws, Ht, Wt, dev, B, scale, max_people, w, c->stream, nullptr)) return -1;
+  if (overflow_dev)
+    PH_CHECK(hipMemcpyAsync(overflow_dev, w.overflow, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
 

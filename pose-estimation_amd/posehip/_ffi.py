@@ -14,6 +14,7 @@ PH_MAX_DST = 8
 PH_OP_CONV, PH_OP_POOL = 0, 1
 PH_ACT_NONE, PH_ACT_RELU, PH_ACT_PRELU = 0, 1, 2
 PH_PRE_CV2, PH_PRE_NATIVE = 0, 1
+PH_NOALLOC_MAX_FRAMES = 8
 
 
 class PhBufDesc(C.Structure):
@@ -94,6 +95,8 @@ SYMBOLS = {
                                    C.POINTER(_vp)]),
     "ph_decode_v2_results": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
     "ph_decode_v2_status": (C.c_int, [_vp]),
+    "ph_decode_v2_noalloc": (C.c_int, [_vp, C.POINTER(PhV2Model), _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_float, C.c_int, _vp, _vp, _vp, _vp]),
     "ph_decode_v2_connections": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ph_decode_v1": (C.c_int, [_vp, C.POINTER(PhV1Model), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                _vp, _vp, _vp, _vp, _vp, _vp]),

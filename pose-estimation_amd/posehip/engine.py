@@ -188,6 +188,24 @@ class Engine:
         decode_v2_results dropped people (more than 2048 partial skeletons in a frame)."""
         _ffi.check(self._lib.ph_decode_v2_status(self._ctx), "ph_decode_v2_status")
 
+    def decode_v2_noalloc(self, model, net_out, Ht, Wt, n_people, keypoints, scores, scale=1.0, overflow=None):
+        """The allocation-free decode: net_out f32 [B,C,Hs,Ws], n_people i32 [B], keypoints f32 [B,M,J,3],
+        scores f32 [B,M] (and overflow i32 [1]) are the caller's CUDA tensors; asynchronous on the engine's stream.
+        At most PH_NOALLOC_MAX_FRAMES BODY_25 frames per call (static 16 MiB workspace per GPU)."""
+        ms, model = self._v2(model)
+        for t in (net_out, n_people, keypoints, scores):
+            if not t.is_cuda or not t.is_contiguous():
+                raise ValueError("decode_v2_noalloc takes contiguous CUDA tensors")
+        B, Cc, Hs, Ws = net_out.shape
+        M = int(keypoints.shape[1])
+        if tuple(keypoints.shape) != (B, M, model.n_parts, 3) or tuple(scores.shape) != (B, M) or n_people.numel() != B:
+            raise ValueError("decode_v2_noalloc: output tensor shapes do not match the batch / model")
+        _ffi.check(self._lib.ph_decode_v2_noalloc(
+            self._ctx, C.byref(ms), C.c_void_p(net_out.data_ptr()), int(B), int(Cc), int(Hs), int(Ws), int(Ht), int(Wt),
+            float(scale), M, C.c_void_p(n_people.data_ptr()), C.c_void_p(keypoints.data_ptr()),
+            C.c_void_p(scores.data_ptr()), C.c_void_p(overflow.data_ptr()) if overflow is not None else None),
+            "ph_decode_v2_noalloc")
+
     def pose_post(self, B, max_people, n_parts, torso_ids=None, depth=None, intr=None, depth_scale=1e-3,
                   patch_offset=2):
         """Torso boxes and / or 3-D lift of the last decode_v2(_dev) results, computed on the device keypoints.
