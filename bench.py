@@ -122,7 +122,8 @@ def main():
 
     from posehip import synth
     src_h, src_w = (int(v) for v in args.frame_size.lower().split("x"))
-    kp_scale = max(src_h / NET_H, src_w / NET_W)   # keep-aspect resize of the native flavour, inverted
+    from posehip.api_native import scale_net_to_output
+    kp_scale = scale_net_to_output(src_w, src_h, NET_W, NET_H)   # OpenPose's mScaleNetToOutput (1.0 at 656x368)
     frames_host = torch.from_numpy(synth.synth_frames(1000 + rank, B, src_h, src_w)).pin_memory()
     J = BODY_25.n_parts
     bufs = []

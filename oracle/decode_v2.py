@@ -360,15 +360,27 @@ def people_array(rows, scores, valid, peaks, model, scale=1.0):
     return kp, sc
 
 
+def scale_net_to_output(image_w, image_h, net_w, net_h):
+    """mScaleNetToOutput of poseExtractorCaffe.cpp::forwardPass (1.7.0), float32: the factor that takes peak
+    coordinates on the net-input-sized maps back to input-image pixels.  s = resizeGetScaleFactor(image, net);
+    netSize = positiveIntRound(s * image); result = float(resizeGetScaleFactor(netSize, image))."""
+    s = min((net_w - 1) / float(image_w - 1), (net_h - 1) / float(image_h - 1))
+    nw, nh = int(s * image_w + 0.5), int(s * image_h + 0.5)
+    return f32(min((image_w - 1) / float(nw - 1), (image_h - 1) / float(nh - 1)))
+
+
 def decode(net_out, model, h_target=None, w_target=None, scale=1.0,
            return_intermediates=False):
-    """Full V2 decode of one frame.  net_out f32 [C, hs, ws]."""
+    """Full V2 decode of one frame.  net_out f32 [C, hs, ws]; scale = mScaleNetToOutput."""
     net_out = np.asarray(net_out, dtype=f32)
     C, hs, ws = net_out.shape
     h_target = h_target or hs * 8
     w_target = w_target or ws * 8
     up = upsample_bicubic(net_out, h_target, w_target)   # upstream materialises all channels
-    peaks = nms(up[:model.n_parts], model.nms_threshold, model.max_peaks)
+    # poseExtractorCaffe.cpp (1.7.0): nmsOffset = float(0.5 / double(mScaleNetToOutput)) -- the half-pixel centre
+    # in units of the OUTPUT image, since the keypoints are multiplied by the scale afterwards
+    off = f32(0.5 / float(f32(scale)))
+    peaks = nms(up[:model.n_parts], model.nms_threshold, model.max_peaks, offset=(off, off))
     maps = up
     conns = [select_connections(peaks, maps, model, k)
              for k in range(model.n_pairs)]

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(1024) void nms_detect_cols_kernel(const float* __re
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void nms_refine_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
                                                          int Ht, int Wt, int max_peaks, int n_parts, int n_split,
-                                                         const int* __restrict__ keys,
+                                                         float offset, const int* __restrict__ keys,
                                                          const int* __restrict__ key_cnt, float* __restrict__ peaks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(128) void nms_refine_kernel(const float* __restrict
         }
       }
     }
-    out[(k + 1) * 3 + 0] = xacc / sacc + 0.5f;
-    out[(k + 1) * 3 + 1] = yacc / sacc + 0.5f;
+    out[(k + 1) * 3 + 0] = xacc / sacc + offset;
+    out[(k + 1) * 3 + 1] = yacc / sacc + offset;
     out[(k + 1) * 3 + 2] = bicubic_tp(s_src, ws, tx[3], pack_taps(src_taps(py, Ht, hs)));
   }
 }
@@ -941,6 +941,10 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
     ph_set_error("decode_v2: target %dx%d must be >= 4x the net output %dx%d", Ht, Wt, hs, ws);
     return -1;
   }
+  if (!(scale > 0.f)) {
+    ph_set_error("decode_v2: keypoint scale %g must be positive", (double)scale);
+    return -1;
+  }
   if (Ht < 3 || Wt < 3 || Wt > 65535 || Ht > 32767) {
     ph_set_error("decode_v2: bad target size %dx%d", Ht, Wt);
     return -1;
@@ -949,6 +953,9 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
     ph_set_error("decode_v2: net output has %d channels, model needs %d", C, m.n_heat + 2 * m.n_pairs);
     return -1;
   }
+  // upstream poseExtractorCaffe.cpp: nmsOffset = float(0.5 / double(mScaleNetToOutput)), so that a peak sits at
+  // the pixel centre (+0.5) in OUTPUT-image units after the keypoints are multiplied by the scale
+  const float nms_offset = (float)(0.5 / (double)scale);
   const int n_split = PH_V2_NMS_SPLIT;
   const int rows_per_split = (((Ht + n_split - 1) / n_split) + NMS_BAND - 1) / NMS_BAND * NMS_BAND;
   // POSEHIP_NMS_BANDS=1: the first form of kernel 1a (upsampled bands through LDS), kept for A/B runs
@@ -1012,7 +1019,8 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
                        w.nms_cnt);
   }
   hipLaunchKernelGGL(nms_refine_kernel, dim3(m.n_parts, B), dim3(128), lds1b, stream, net_out, C, hs, ws, Ht, Wt,
-                     m.max_peaks, m.n_parts, n_split, (const int*)w.nms_keys, (const int*)w.nms_cnt, w.peaks);
+                     m.max_peaks, m.n_parts, n_split, nms_offset, (const int*)w.nms_keys, (const int*)w.nms_cnt,
+                     w.peaks);
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(paf_coef ? paf_score_kernel<true> : paf_score_kernel<false>, dim3(m.n_pairs, B, paf_sub),
                      dim3(PAF_THREADS), lds2, stream, net_out, C, hs, ws, Ht, Wt, (const float*)w.peaks, m,

@@ -7,9 +7,12 @@
 // OpenCV 4.5.x resize.cpp -- unverified against a real cv2, none is available),
 // then * 1/255.
 // PH_PRE_NATIVE replaces OpenPose's cvMatToOpInput inside emplaceAndPop
-// (openpose/native/python/skeleton.py:447): keep-aspect scale anchored at the
-// top-left, zero fill, bilinear with source coordinates quantised to 1/32 px
-// as cv::warpAffine does, then x/256 - 0.5.
+// (openpose/native/python/skeleton.py:447): resizeFixedAspectRatio = cv::warpAffine
+// with the matrix diag(s, s), s = min((Wn-1)/(W0-1), (Hn-1)/(H0-1)), zero fill,
+// INTER_LINEAR for s <= 1 (OpenPose asks for INTER_AREA, which warpAffine replaces)
+// and INTER_CUBIC for s > 1, in OpenCV's fixed point (1/32-px phases, 15-bit
+// weights, (sum + 16384) >> 15), then x/256 - 0.5.  Bit-exact against
+// oracle/preprocess.py:cv_mat_to_op_input, which states the sources.
 #include "common.h"
 
 __device__ __forceinline__ int cv_round_short(float v) {
@@ -17,8 +20,17 @@ __device__ __forceinline__ int cv_round_short(float v) {
   return r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
 }
 
+// OpenCV interpolateCubic (A = -0.75), fp32
+__device__ __forceinline__ void cubic_coeffs(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
 __global__ void preprocess_kernel(const uint8_t* __restrict__ frames, int B, int H0, int W0, int Hn, int Wn,
-                                  int mode, double scale_x, double scale_y, double inv_scale,
+                                  int mode, double scale_x, double scale_y, double inv_scale, int cubic,
                                   bf16* __restrict__ out, int out_Hp, int out_Wp, int out_Cs, int out_org) {
   const size_t total = (size_t)B * Hn * Wn;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
@@ -59,20 +71,64 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ frames, int B, int
       }
       for (int c = 0; c < 3; c++) v[c] = v[c] * (1.0f / 255.0f);
     } else {
-      // source position = dst / scale, quantised to 1/32 px
-      const int X = __double2int_rn(x * inv_scale * 32.0), Y = __double2int_rn(y * inv_scale * 32.0);
-      const int sx = X >> 5, sy = Y >> 5;
-      const float fx = (float)(X & 31) * (1.f / 32.f), fy = (float)(Y & 31) * (1.f / 32.f);
-      for (int c = 0; c < 3; c++) {
-        float p[4];
+      // cv::warpAffine's fixed-point source coordinates: AB_BITS = 10, round_delta = 16, 1/32-px phases
+      const int X = (int)((16 + __double2ll_rn(inv_scale * (double)x * 1024.0)) >> 5);
+      const int Y = (int)((16 + __double2ll_rn((inv_scale * (double)y + 0.0) * 1024.0)) >> 5);
+      const int ax = X & 31, ay = Y & 31;
+      int acc[3] = {0, 0, 0};
+      if (!cubic) {
+        const int sx = X >> 5, sy = Y >> 5;
+        // BilinearTab_i[ay*32 + ax]: exact products (32-ay)(32-ax)*32 ...; entry 0 is {32767, 0, 0, 1} (the
+        // saturated 32768 and the library's sum fix-up)
+        int w[4] = {(32 - ay) * (32 - ax) * 32, (32 - ay) * ax * 32, ay * (32 - ax) * 32, ay * ax * 32};
+        if ((ax | ay) == 0) {
+          w[0] = 32767;
+          w[3] = 1;
+        }
         for (int k = 0; k < 4; k++) {
           const int xx = sx + (k & 1), yy = sy + (k >> 1);
-          p[k] = (xx >= 0 && xx < W0 && yy >= 0 && yy < H0) ? (float)img[((size_t)yy * W0 + xx) * 3 + c] : 0.f;
+          if (xx >= 0 && xx < W0 && yy >= 0 && yy < H0) {
+            const uint8_t* p = img + ((size_t)yy * W0 + xx) * 3;
+            for (int c = 0; c < 3; c++) acc[c] += (int)p[c] * w[k];
+          }
         }
-        const float top = p[0] * (1.f - fx) + p[1] * fx, bot = p[2] * (1.f - fx) + p[3] * fx;
-        const float val = top * (1.f - fy) + bot * fy;
-        v[c] = floorf(val + 0.5f);  // back to u8 as warpAffine does
-        v[c] = v[c] * (1.0f / 256.0f) - 0.5f;
+      } else {
+        const int sx = (X >> 5) - 1, sy = (Y >> 5) - 1;
+        float cx[4], cy[4];
+        cubic_coeffs((float)ax * (1.0f / 32), cx);
+        cubic_coeffs((float)ay * (1.0f / 32), cy);
+        int w[16], isum = 0;
+        for (int i = 0; i < 4; i++)
+          for (int j = 0; j < 4; j++) {
+            w[i * 4 + j] = cv_round_short((cy[i] * cx[j]) * 32768.0f);
+            isum += w[i * 4 + j];
+          }
+        if (isum != 32768) {  // initInterTab2D's fix-up over rows/columns 2..3 of the 4x4 weights
+          const int diff = isum - 32768;
+          int Mk = 10, mk = 10;
+          for (int k1 = 2; k1 < 4; k1++)
+            for (int k2 = 2; k2 < 4; k2++) {
+              const int q = k1 * 4 + k2;
+              if (w[q] < w[mk]) mk = q;
+              else if (w[q] > w[Mk]) Mk = q;
+            }
+          if (diff < 0) w[Mk] -= diff;
+          else w[mk] -= diff;
+        }
+        for (int i = 0; i < 4; i++) {
+          const int yy = sy + i;
+          if (yy < 0 || yy >= H0) continue;
+          for (int j = 0; j < 4; j++) {
+            const int xx = sx + j;
+            if (xx < 0 || xx >= W0) continue;
+            const uint8_t* p = img + ((size_t)yy * W0 + xx) * 3;
+            for (int c = 0; c < 3; c++) acc[c] += (int)p[c] * w[i * 4 + j];
+          }
+        }
+      }
+      for (int c = 0; c < 3; c++) {
+        const int d = (acc[c] + 16384) >> 15;  // FixedPtCast<int, uchar, 15>
+        v[c] = (float)(d < 0 ? 0 : (d > 255 ? 255 : d)) * (1.0f / 256.0f) - 0.5f;
       }
     }
     bf16x8 o;
@@ -85,14 +141,18 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ frames, int B, int
 int ph_launch_preprocess(const uint8_t* frames, int B, int H0, int W0, int Hn, int Wn, int mode, bf16* out,
                          int out_Hp, int out_Wp, int out_Cs, int out_org, hipStream_t stream) {
   const double scale_x = (double)W0 / Wn, scale_y = (double)H0 / Hn;
+  // OpenPose resizeGetScaleFactor, then the inverse matrix entry as cv::warpAffine computes it (D = 1/(s*s), s*D)
   double s = (Wn - 1) / (double)(W0 - 1 > 0 ? W0 - 1 : 1);
   const double s2 = (Hn - 1) / (double)(H0 - 1 > 0 ? H0 - 1 : 1);
   s = s < s2 ? s : s2;
+  double D = s * s;
+  D = D != 0 ? 1. / D : 0;
+  const double inv = s * D;
   const size_t total = (size_t)B * Hn * Wn;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, stream, frames, B, H0, W0, Hn, Wn, mode,
-                     scale_x, scale_y, 1.0 / s, out, out_Hp, out_Wp, out_Cs, out_org);
+                     scale_x, scale_y, inv, s > 1.0 ? 1 : 0, out, out_Hp, out_Wp, out_Cs, out_org);
   PH_CHECK(hipGetLastError());
   return 0;
 }

@@ -56,19 +56,28 @@ class Datum:
 
 
 def net_input_size(net_resolution: str, image_w: int, image_h: int) -> Tuple[int, int]:
-    """OpenPose ``--net_resolution`` semantics: "WxH", multiples of 16, one of
-    them may be -1 = keep the image aspect ratio, rounded UP to a multiple of 16
-    (1920x1080 at "-1x368" -> 656x368)."""
+    """OpenPose ``--net_resolution`` semantics: "WxH", multiples of 16; a side given as -1 follows the image aspect
+    ratio and is ROUNDED to the nearest multiple of 16 in float32, as upstream ``ScaleAndSizeExtractor::extract``
+    does: ``16 * positiveIntRound(1/16.f * h * W0 / (float)H0)`` (1920x1080 at "-1x368": 654.2 -> 656)."""
     w, h = (int(v) for v in net_resolution.lower().split("x"))
     if w <= 0 and h <= 0:
         raise ValueError(f"net_resolution {net_resolution!r}: width and height cannot both be -1")
+    f32 = np.float32
     if w <= 0:
-        w = int(16 * math.ceil(h * image_w / float(image_h) / 16.0))
+        w = 16 * int(f32(f32(f32(1) / f32(16)) * f32(h)) * f32(image_w) / f32(image_h) + f32(0.5))
     elif h <= 0:
-        h = int(16 * math.ceil(w * image_h / float(image_w) / 16.0))
-    if w % 16 or h % 16:
+        h = 16 * int(f32(f32(f32(1) / f32(16)) * f32(w)) * f32(image_h) / f32(image_w) + f32(0.5))
+    if w % 16 or h % 16 or w < 16 or h < 16:
         raise ValueError(f"net_resolution {net_resolution!r} must be multiples of 16")
     return w, h
+
+
+def scale_net_to_output(image_w: int, image_h: int, net_w: int, net_h: int) -> float:
+    """Upstream ``mScaleNetToOutput`` (poseExtractorCaffe.cpp forwardPass): keypoints on the net-input-sized maps
+    -> input-image pixels.  Not 1/s: OpenPose rounds the scaled image size to whole pixels first."""
+    s = min((net_w - 1) / float(max(image_w - 1, 1)), (net_h - 1) / float(max(image_h - 1, 1)))
+    nw, nh = int(s * image_w + 0.5), int(s * image_h + 0.5)
+    return float(np.float32(min((image_w - 1) / float(max(nw - 1, 1)), (image_h - 1) / float(max(nh - 1, 1)))))
 
 
 class Wrapper:
@@ -198,8 +207,7 @@ class Wrapper:
             eng.preprocess(np.stack(frames), _ffi.PH_PRE_NATIVE)
             eng.forward(B)
             raw = eng.net_out(B) if self.want_raw else None
-        s_in = min((net_w - 1) / max(W0 - 1, 1), (net_h - 1) / max(H0 - 1, 1))
-        scale = 1.0 / s_in
+        scale = scale_net_to_output(W0, H0, net_w, net_h)
         res, _ = eng.decode_v2(model, B, net_h, net_w, scale=scale,
                                max_people=int(p.get("number_people_max", 0)) or 128)
         want_hm = p.get("heatmaps_add_parts") or p.get("heatmaps_add_bkg") or p.get("heatmaps_add_PAFs")

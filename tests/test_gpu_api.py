@@ -47,7 +47,7 @@ def test_native_estimator_end_to_end(tmp_path):
     img = synth.synth_frames(0, 1, 96, 160)[0]
     pyop.predict(img)
     pyop.filter_prediction()
-    assert pyop.datum.netInputSizes[0].x == 224 and pyop.datum.netInputSizes[0].y == 128   # 128*160/96=213.3 -> 224
+    assert pyop.datum.netInputSizes[0].x == 208 and pyop.datum.netInputSizes[0].y == 128   # 128*160/96/16 = 13.3 -> 13
     assert pyop.opencv_image.shape == img.shape
     if pyop.pose_empty:
         assert pyop.pose_scores is None and pyop.pose_bounding_box is None
@@ -60,7 +60,7 @@ def test_native_estimator_end_to_end(tmp_path):
     pyop.predict_hm(img, hm_path)
     kp0 = None if pyop.pose_empty else pyop.pose_keypoints.copy()
     hm = api_native.read_heatmap_file(hm_path)
-    assert hm[0].shape == (1, 78, 16, 28)
+    assert hm[0].shape == (1, 78, 16, 26)
     pyop.predict_from_hm(img, hm)
     kp1 = None if pyop.pose_empty else pyop.pose_keypoints
     assert (kp0 is None) == (kp1 is None)
@@ -160,9 +160,47 @@ def test_preprocess_modes_match_restated_cv2(engine):
     np.testing.assert_array_equal(got.view(np.uint32), ref16)
     engine.preprocess(big, _ffi.PH_PRE_NATIVE)                       # keep-aspect, x/256-0.5, zero fill -> -0.5
     nat = engine.get_buffer(0)[:, 1:-1, 1:-1, :3]
-    assert nat.min() >= -0.5 and nat.max() <= 0.5
+    want = pre_ref.cv_mat_to_op_input(big, 40, 24).transpose(0, 2, 3, 1)
+    np.testing.assert_array_equal(nat, want)                         # multiples of 1/256: exact in bf16
     s = min(39 / 76, 23 / 50)
     assert (nat[:, :, int(77 * s) + 2:] == -0.5).all()               # right of the scaled image: filled with 0 -> -0.5
+
+
+@pytest.mark.parametrize("src_hw,net_hw,real", [
+    ((1080, 1920), (368, 656), False),     # BASELINE configs[4]: 1080p stream at "-1x368" (linear, s = 0.3401)
+    ((480, 480), (368, 368), False),       # the reference's cv2 bench frame size (opencv/inference.py:67), s = 0.766
+    ((384, 384), (368, 368), False),       # native/python/test.py:34-35
+    ((431, 577), (368, 496), False),       # non-integer down-scale with a filled margin
+    ((200, 301), (368, 560), False),       # up-scale: s = 1.836 > 1 -> INTER_CUBIC
+    ((368, 656), (368, 656), False),       # same size: copy
+    ((368, 368), (368, 656), True),        # data/test/pillar_text.jpg into a wider net: s = 1, zero fill
+    ((0, 0), (368, 496), True),            # data/sample/COCO_val2014_000000000192.jpg (480x640), s = 0.766
+])
+def test_native_preprocess_matches_restated_cvMatToOpInput(engine, src_hw, net_hw, real):
+    """PH_PRE_NATIVE (first kernel of the headline path and of Wrapper.emplaceAndPop) against
+    oracle/preprocess.py:cv_mat_to_op_input = OpenPose resizeFixedAspectRatio (cv::warpAffine, linear for
+    s <= 1, cubic for s > 1, zero fill) + x/256 - 0.5, bit-exact (integer fixed point; the values are multiples of
+    1/256 in [-0.5, 0.5), exact in bf16)."""
+    import os
+    from oracle import preprocess as pre_ref
+    Hn, Wn = net_hw
+    if real:
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "real_images.npz"))
+        frames = g["pillar_text_bgr" if src_hw[0] else "coco_192_bgr"][None]
+    else:
+        frames = synth.synth_frames(src_hw[0] * 7 + src_hw[1], 2, src_hw[0], src_hw[1])
+    net = caffe_io.parse_prototxt(f'input: "image" input_dim: 1 input_dim: 3 input_dim: {Hn} input_dim: {Wn}\n' +
+                                  caffe_io._conv("out", "image", 8, 3))
+    engine.build(graph.build_plan(net, graph.random_weights(net, 0)), len(frames))
+    engine.preprocess(frames, _ffi.PH_PRE_NATIVE)
+    got = engine.get_buffer(0)
+    want = pre_ref.cv_mat_to_op_input(frames, Wn, Hn).transpose(0, 2, 3, 1)
+    np.testing.assert_array_equal(got[:, 1:-1, 1:-1, :3], want)
+    assert (got[:, 0] == 0).all() and (got[:, :, -1] == 0).all() and (got[..., 3:] == 0).all()
+    if not real:   # the same frames from device memory
+        import torch
+        engine.preprocess(torch.from_numpy(frames).cuda(), _ffi.PH_PRE_NATIVE)
+        np.testing.assert_array_equal(engine.get_buffer(0)[:, 1:-1, 1:-1, :3], want)
 
 
 def test_real_images_preprocess_matches_golden(engine):

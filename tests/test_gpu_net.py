@@ -169,3 +169,38 @@ def test_fused_pool_and_kernel_names(engine):
     podd.ops[1]["pool"] = 1                                                # forcing it must fail loudly
     with pytest.raises(_ffi.PosehipError):
         engine.build(podd, 1)
+
+
+def test_body25_batch32_production_tiles_meet_the_oracle(engine):
+    """The instantiations bench.py times (B = 32: 128- and 96-wide N tiles on the 46x82 stage layers, which
+    smaller batches narrow to 32/64) against the oracle: frame k of the batch of 32 is bit-equal to the same
+    frame run alone (different tile selection, same K order), and that run is within 1e-2 of the torch fp32
+    oracle -- so the benched kernels meet the oracle transitively; two frames are also compared directly."""
+    from oracle import net_ref
+    from posehip import synth
+    H, W, B = 368, 656, 32
+    net = caffe_io.parse_prototxt(caffe_io.body25_prototxt(H, W))
+    weights = graph.random_weights(net, seed=9)
+    plan = graph.build_plan(net, weights)
+    engine.build(plan, B)
+    names = engine.op_kernels()
+    assert names.count("conv3x3_halo_kernel<4, 4, false, false, 9>") == 70      # the dominant kernel of the bench
+    assert names.count("conv3x3_halo_kernel<3, 4, false, false, 9>") == 30
+    assert names.count("conv3x3_halo_kernel<2, 4, false, true, 9>") == 1        # stem (conv1_1 + conv1_2 + pool)
+    frames = synth.synth_frames(77, B, H, W)
+    engine.preprocess(frames, _ffi.PH_PRE_NATIVE)
+    engine.forward(B)
+    got = engine.net_out(B)
+    assert np.isfinite(got).all()
+    for k in (0, 13, 31):
+        x = frames[k:k + 1].astype(np.float32).transpose(0, 3, 1, 2) * np.float32(1 / 256.0) - np.float32(0.5)
+        if k != 13:
+            ref = net_ref.forward(net, weights, x)
+            err = np.abs(got[k] - ref[0]).max()
+            assert err < 1e-2, (k, err)
+    engine.build(plan, 1)                         # single-frame tile selection (narrow N tiles)
+    assert engine.op_kernels() != names
+    for k in (0, 13, 31):
+        engine.preprocess(frames[k:k + 1], _ffi.PH_PRE_NATIVE)
+        engine.forward(1)
+        np.testing.assert_array_equal(engine.net_out(1)[0], got[k])

@@ -122,6 +122,10 @@ def test_net_input_size():
     assert api_native.net_input_size("-1x368", 384, 384) == (368, 368)
     assert api_native.net_input_size("656x368", 100, 100) == (656, 368)
     assert api_native.net_input_size("320x-1", 640, 480) == (320, 240)
+    assert api_native.net_input_size("-1x368", 497, 368) == (496, 368)     # 31.06 sixteenths: rounded, not ceiled
+    from oracle import preprocess as pre_ref
+    for wh in ((1920, 1080), (640, 480), (497, 368), (1280, 720), (333, 500)):
+        assert api_native.net_input_size("-1x368", *wh) == pre_ref.op_net_input_size("-1x368", *wh)
     with pytest.raises(ValueError):
         api_native.net_input_size("-1x-1", 10, 10)
     with pytest.raises(ValueError):

@@ -151,3 +151,40 @@ def test_preprocess_restatement_known_answers_and_fixture():
     for tag in ("pillar_text", "coco_192"):
         got = preprocess.cv_resize_u8(g[tag + "_bgr"][None], 656, 368)[0]
         np.testing.assert_array_equal(got, g[tag + "_resized_656x368"])
+
+
+# ---- native-flavour preprocess (OpenPose cvMatToOpInput = cv::warpAffine in fixed point) -----------------------
+def test_native_preprocess_oracle_known_answers():
+    from oracle import preprocess as P
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (1, 9, 13, 3), dtype=np.uint8)
+    # scale 1 into a larger canvas: the frame is copied to the top-left corner, the rest is the border value 0
+    out = P.op_resize_fixed_aspect(np.pad(img, ((0, 0), (0, 0), (0, 0), (0, 0))), 13, 9)
+    np.testing.assert_array_equal(out, img)
+    wide = P.warp_affine_scale_u8(img, 1.0, 16, 9)
+    np.testing.assert_array_equal(wide[:, :, :13], img)
+    assert (wide[:, :, 13:] == 0).all()
+    # exact 2:1 down-scale: s = (Wn-1)/(W0-1) is NOT 1/2 (OpenPose's "-1" convention), so pixel x maps to
+    # x * (W0-1)/(Wn-1); with a 17 -> 9 pixel row that is exactly 2x and every output pixel is a source pixel
+    row = rng.integers(0, 256, (1, 17, 17, 3), dtype=np.uint8)
+    half = P.op_resize_fixed_aspect(row, 9, 9)
+    np.testing.assert_array_equal(half, row[:, ::2, ::2])
+    # half-way phases: 5 -> 9 pixels is s = 2 > 1 -> INTER_CUBIC; odd outputs sit half-way between sources:
+    # weights (-0.09375, 0.59375, 0.59375, -0.09375) = OpenCV's cubic (A = -0.75) at 0.5, taps outside are 0
+    ramp = np.zeros((1, 5, 5, 3), np.uint8)
+    ramp[0, :, :, :] = (np.arange(5) * 40)[None, :, None]
+    up = P.op_resize_fixed_aspect(ramp, 9, 9)
+    np.testing.assert_array_equal(up[0, 0, ::2, 0], np.arange(5) * 40)
+    assert up[0, 0, 3, 0] == 60            # interior: the cubic reproduces a linear ramp
+    assert up[0, 0, 1, 0] == int(np.floor(0.59375 * 40 - 0.09375 * 80 + 0.5))     # left tap outside -> 0
+    # the fixed-point tables: every 2-D weight set sums to 1.0 (32768); entry (0, 0) is the saturated 32767 + 1
+    lin, cub = P._inter_tab_2d(False), P._inter_tab_2d(True)
+    assert (lin.reshape(1024, -1).sum(1) == 32768).all() and (cub.reshape(1024, -1).sum(1) == 32768).all()
+    assert lin[0].tolist() == [[32767, 0], [0, 1]] and lin[33].tolist() == [[30752, 992], [992, 32]]
+    assert cub[0, 1, 1] == 32767 and cub[0, 2, 2] == 1
+    # normalisation: (x / 256) - 0.5, CHW
+    blob = P.cv_mat_to_op_input(img, 13, 9)
+    assert blob.shape == (1, 3, 9, 13)
+    np.testing.assert_array_equal(blob[0, :, 2, 3], img[0, 2, 3].astype(np.float32) / 256 - 0.5)
+    assert P.op_net_input_size("-1x368", 1920, 1080) == (656, 368)
+    assert P.op_scale_factor(1920, 1080, 656, 368) == min(655 / 1919, 367 / 1079)
