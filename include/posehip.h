@@ -80,6 +80,10 @@ typedef struct {
   float nms_threshold, inter_threshold, inter_min_above_threshold, min_subset_score;
   int pairs[64 * 2];  /* limb (partA, partB) */
   int mapidx[64 * 2]; /* PAF channel pair per limb, relative to n_heat */
+  int connector;      /* person assembly of upstream bodyPartConnector: 1 = what a CUDA build of OpenPose runs
+                         (pafPtrIntoVector + pafVectorIntoPeopleVector: one score-sorted walk over all candidate
+                         pairs with assign / extend / merge-if-disjoint) -- the reference's Docker image builds
+                         that; 0 = what a CPU-only build runs (per-limb sorted greedy + createPeopleVector) */
 } ph_v2_model;
 
 /* In-tree decode constants ("V1"; openpose/opencv/common.py MAPIDX :26-28 and
@@ -170,7 +174,7 @@ int ph_decode_v2_status(ph_ctx* ctx);
  * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
  * Same kernels and results as ph_decode_v2_dev, but the net output is the caller's device buffer
  * (f32 [B][C][Hs][Ws]), the results go to the caller's device buffers (shapes as above) and the workspace (peak
- * tables, PAF score matrices, connection lists) lives in a 16 MiB static device array of the library, one per GPU,
+ * tables, PAF score matrices, connection lists) lives in a 20 MiB static device array of the library, one per GPU,
  * held until the process ends.  Limit: B <= PH_NOALLOC_MAX_FRAMES and the workspace of the B frames must fit the
  * array (it does for BODY_25 / COCO with 127 peaks per part); larger calls return -3 and launch nothing.  Asynchronous on the ctx stream.
  * overflow_dev (device int32, may be NULL) receives 1 when a frame had more than 2048 partial skeletons.

@@ -4,8 +4,9 @@ CPU restatement, in NumPy float32, of the decode that runs inside
 ``op.WrapperPython.emplaceAndPop`` on the reference's native path
 (``openpose/native/python/skeleton.py:444-450``): net output -> bicubic x8
 upsample -> 3x3 NMS with 7x7 sub-pixel refine -> PAF line-integral limb scoring
--> sorted greedy per-limb matching -> person assembly -> person filter ->
-``poseKeypoints [M,J,3]`` / ``poseScores [M]``.
+-> person assembly (two upstream routes: per-limb sorted greedy matching + createPeopleVector in CPU builds;
+one globally sorted connection list with assign / extend / merge-if-disjoint in CUDA builds, which is what the
+reference's Docker image runs) -> person filter -> ``poseKeypoints [M,J,3]`` / ``poseScores [M]``.
 
 PARITY UNPINNED.  That arithmetic lives in the third-party OpenPose library
 (author's fork ``cheneeheng/openpose`` branch ``devel``, no commit pin,
@@ -135,10 +136,21 @@ def _pir(x):
     return int(f32(f32(x) + f32(0.5)))
 
 
-def score_ab(a, b, map_x, map_y, inter_threshold, inter_min_above, nms_thr):
+def _close_thr(W, H, cuda):
+    """Distance below which two unconnected peaks still get the minimum PAF score: sqrt(W*H)/150, evaluated in
+    double by the CPU connector (bodyPartConnectorBase.cpp getScoreAB) and in float by the CUDA one
+    (bodyPartConnectorBase.cu process(): sqrtf(w*h)/150, compared with the float distance)."""
+    if cuda:
+        return float(f32(np.sqrt(f32(W * H))) / f32(150.0))
+    return np.sqrt(float(W * H)) / 150.0
+
+
+def score_ab(a, b, map_x, map_y, inter_threshold, inter_min_above, nms_thr, cuda=False):
     """a, b = (x, y, score) fp32 rows; map_x/map_y f32 [H, W] upsampled PAFs.
 
-    Returns fp32 score (0 when rejected), as upstream getScoreAB.
+    Returns fp32 score (0 when rejected), as upstream getScoreAB (cuda=True: the CUDA build's process(), which
+    differs only in the precision of the close-keypoint threshold and returns -1 instead of 0 when rejected --
+    both are discarded by the `> 1e-6` test of their callers).
     """
     H, W = map_x.shape
     vx = f32(b[0] - a[0])
@@ -165,13 +177,13 @@ def score_ab(a, b, map_x, map_y, inter_threshold, inter_min_above, nms_thr):
             return f32(total / f32(count))
         # close-keypoint rescue (1.7.0): minimum PAF score for near-coincident
         l2 = norm
-        thr = np.sqrt(float(W * H)) / 150.0                 # double, as upstream
+        thr = _close_thr(W, H, cuda)
         if float(l2) < thr:
             return f32(float(f32(nms_thr)) + 1e-6)
     return f32(0.0)
 
 
-def pair_scores(cand_a, cand_b, map_x, map_y, inter_threshold, inter_min_above, nms_thr):
+def pair_scores(cand_a, cand_b, map_x, map_y, inter_threshold, inter_min_above, nms_thr, cuda=False):
     """Vectorised score_ab over all (i, j): cand_a f32 [nA,3], cand_b f32 [nB,3]
     -> f32 [nA, nB].  Same fp32 operations, element-wise, as score_ab."""
     H, W = map_x.shape
@@ -210,7 +222,7 @@ def pair_scores(cand_a, cand_b, map_x, map_y, inter_threshold, inter_min_above, 
     good = ok & ((cf / nf).astype(f32) > f32(inter_min_above))
     with np.errstate(divide="ignore", invalid="ignore"):
         avg = (total / cf).astype(f32)
-    close = ok & ~good & (norm.astype(np.float64) < np.sqrt(float(W * H)) / 150.0)
+    close = ok & ~good & (norm.astype(np.float64) < _close_thr(W, H, cuda))
     out = np.zeros_like(vx)
     out = np.where(good, avg, out)
     out = np.where(close, f32(float(f32(nms_thr)) + 1e-6), out)
@@ -325,6 +337,90 @@ def assemble(peaks, connections, model):
     return rows, np.asarray(scores, dtype=f32)
 
 
+# ---------------------------------------------------------------------------
+# The CUDA build's connector (upstream bodyPartConnectorBase.cu connectBodyPartsGpu ->
+# bodyPartConnectorBase.cpp pafPtrIntoVector + pafVectorIntoPeopleVector).  This is the route the reference's
+# Docker image runs (docker/openpose/dockerfiles/Dockerfile.U20:66-95 builds OpenPose with CUDA), reached from
+# openpose/native/python/skeleton.py:447.  createPeopleVector above is what a CPU-only / OpenCL build runs.
+# ---------------------------------------------------------------------------
+
+def paf_ptr_into_vector(peaks, maps, model):
+    """pafPtrIntoVector: every (limb, A_i, B_j) whose PAF score passes `> 1e-6`, as
+    (totalScore, pafScore, pairIndex, indexA, indexB) with totalScore = paf + 0.1 * scoreA + 0.1 * scoreB (fp32,
+    left to right), sorted descending as std::greater<std::tuple<double, double, int, int, int>>."""
+    conns = []
+    for k, (part_a, part_b) in enumerate(model.pairs):
+        na = _pir(peaks[part_a, 0, 0])
+        nb = _pir(peaks[part_b, 0, 0])
+        if na == 0 or nb == 0:
+            continue
+        ch_x = model.n_heat + model.mapidx[k][0]
+        ch_y = model.n_heat + model.mapidx[k][1]
+        sc = pair_scores(peaks[part_a, 1:na + 1], peaks[part_b, 1:nb + 1], maps[ch_x], maps[ch_y],
+                         model.inter_threshold, model.inter_min_above_threshold, model.nms_threshold, cuda=True)
+        ii, jj = np.nonzero(sc.astype(np.float64) > 1e-6)
+        for i, j in zip(ii, jj):
+            paf = f32(sc[i, j])
+            total = f32(f32(paf + f32(f32(0.1) * peaks[part_a, i + 1, 2])) + f32(f32(0.1) * peaks[part_b, j + 1, 2]))
+            conns.append((float(total), float(paf), k, int(i) + 1, int(j) + 1))
+    conns.sort(reverse=True)
+    return conns
+
+
+def paf_vector_into_people_vector(conns, peaks, model):
+    """pafVectorIntoPeopleVector: walk the globally sorted connections once; per connection
+      1. neither end assigned     -> new person {A, B}
+      2./3. one end assigned      -> add the other end to that person unless it already has that part
+      4. both ends, same person   -> add the PAF score to the person (redundant limb of a cycle)
+      5. both ends, two people    -> merge them when they share no part (the lower index survives)
+    People emptied by a merge are removed at the end; order = creation order.
+    Returns (rows int32 [R, n_parts+1], scores f32 [R])."""
+    n_parts, mp = model.n_parts, model.max_peaks
+    off = 3 * (mp + 1)
+    flat = peaks.reshape(-1)
+    rows, scores = [], []
+    assigned = np.full((n_parts * mp,), -1, np.int64)
+    for _total, paf, k, ia, ib in conns:
+        paf = f32(paf)
+        part_a, part_b = model.pairs[k]
+        idx_a = part_a * off + ia * 3 + 2
+        idx_b = part_b * off + ib * 3 + 2
+        sa, sb = part_a * mp + ia - 1, part_b * mp + ib - 1
+        pa, pb = int(assigned[sa]), int(assigned[sb])
+        if pa < 0 and pb < 0:
+            r = [0] * (n_parts + 1)
+            r[part_a] = idx_a
+            r[part_b] = idx_b
+            r[-1] = 2
+            assigned[sa] = assigned[sb] = len(rows)
+            rows.append(r)
+            scores.append(f32(f32(flat[idx_a] + flat[idx_b]) + paf))
+        elif (pa >= 0) != (pb >= 0):
+            p1 = pa if pa >= 0 else pb
+            part2, idx2, slot2 = (part_b, idx_b, sb) if pa >= 0 else (part_a, idx_a, sa)
+            if rows[p1][part2] == 0:
+                rows[p1][part2] = idx2
+                rows[p1][-1] += 1
+                scores[p1] = f32(scores[p1] + f32(flat[idx2] + paf))
+                assigned[slot2] = p1
+        elif pa == pb:
+            scores[pa] = f32(scores[pa] + paf)
+        else:
+            p1, p2 = min(pa, pb), max(pa, pb)
+            if not any(rows[p1][q] > 0 and rows[p2][q] > 0 for q in range(n_parts)):
+                for q in range(n_parts):
+                    if rows[p1][q] == 0:
+                        rows[p1][q] = rows[p2][q]
+                rows[p1][-1] += rows[p2][-1]
+                scores[p1] = f32(scores[p1] + f32(scores[p2] + paf))
+                rows[p2][-1] = 0
+                scores[p2] = f32(0.0)
+                assigned[assigned == p2] = p1
+    keep = [p for p in range(len(rows)) if rows[p][-1] != 0]
+    rows = np.asarray([rows[p] for p in keep], dtype=np.int32).reshape(-1, n_parts + 1)
+    return rows, np.asarray([scores[p] for p in keep], dtype=f32)
+
+
 def filter_people(rows, scores, model, maximize_positives=False):
     """removePeopleBelowThresholdsAndFillFaces -> valid row indices."""
     valid = []
@@ -370,8 +466,10 @@ def scale_net_to_output(image_w, image_h, net_w, net_h):
 
 
 def decode(net_out, model, h_target=None, w_target=None, scale=1.0,
-           return_intermediates=False):
-    """Full V2 decode of one frame.  net_out f32 [C, hs, ws]; scale = mScaleNetToOutput."""
+           return_intermediates=False, connector=None):
+    """Full V2 decode of one frame.  net_out f32 [C, hs, ws]; scale = mScaleNetToOutput.
+    connector: 0 = createPeopleVector (CPU / OpenCL builds of OpenPose), 1 = pafPtrIntoVector +
+    pafVectorIntoPeopleVector (CUDA builds: what the reference's Docker image runs); None = model.connector."""
     net_out = np.asarray(net_out, dtype=f32)
     C, hs, ws = net_out.shape
     h_target = h_target or hs * 8
@@ -382,9 +480,15 @@ def decode(net_out, model, h_target=None, w_target=None, scale=1.0,
     off = f32(0.5 / float(f32(scale)))
     peaks = nms(up[:model.n_parts], model.nms_threshold, model.max_peaks, offset=(off, off))
     maps = up
-    conns = [select_connections(peaks, maps, model, k)
-             for k in range(model.n_pairs)]
-    rows, scores = assemble(peaks, conns, model)
+    if connector is None:
+        connector = getattr(model, "connector", 0)
+    if connector == 1:
+        conns = paf_ptr_into_vector(peaks, maps, model)
+        rows, scores = paf_vector_into_people_vector(conns, peaks, model)
+    else:
+        conns = [select_connections(peaks, maps, model, k)
+                 for k in range(model.n_pairs)]
+        rows, scores = assemble(peaks, conns, model)
     valid = filter_people(rows, scores, model)
     kp, sc = people_array(rows, scores, valid, peaks, model, scale)
     if return_intermediates:

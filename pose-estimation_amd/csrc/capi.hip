@@ -45,7 +45,7 @@ static thread_local char g_err[1024] = "";
 // Workspace of ph_decode_v2_noalloc (the one entry point that allocates nothing).  In host code the name `scratch`
 // is only a handle for hipGetSymbolAddress: the device address of each GPU's own copy is looked up once per device
 // in ph_create (that device current) and kept in g_scratch_ptr; host code uses that pointer everywhere.
-#define PH_SCRATCH_BYTES (16u << 20)
+#define PH_SCRATCH_BYTES (20u << 20)
 static __device__ __align__(256) unsigned char scratch[PH_SCRATCH_BYTES];
 static void* g_scratch_ptr[PH_MAX_DEVICES];
 static std::mutex g_scratch_mu;
@@ -204,7 +204,8 @@ static void free_net(ph_ctx* c) {
 
 static void free_v2(ph_ctx* c) {
   void* ptrs[] = {c->v2.nms_keys, c->v2.nms_cnt, c->v2.peaks,    c->v2.pair_scores, c->v2.conn_idx, c->v2.conn_score, c->v2.n_conn,
-                  c->v2.n_people, c->v2.keypoints,   c->v2.scores,   c->v2.subsets,    c->v2.overflow};
+                  c->v2.n_people, c->v2.keypoints,   c->v2.scores,   c->v2.subsets,    c->v2.overflow,
+                  c->v2.n_accept, c->v2.mrg_lists};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   c->v2 = PhV2Buffers{};
@@ -763,7 +764,9 @@ static int v2_model_to_dev(const ph_v2_model* m, int C, int Ht, int Wt, PhV2Dev*
   dev->inter_min_above = m->inter_min_above_threshold;
   dev->min_subset_score = m->min_subset_score;
   dev->close_score = (float)((double)m->nms_threshold + 1e-6);
-  dev->close_thr = sqrt((double)(Wt * Ht)) / 150.0;
+  dev->connector = m->connector;
+  // bodyPartConnectorBase.cpp getScoreAB: std::sqrt(area) / 150 in double; .cu process(): sqrtf(w * h) / 150 in float
+  dev->close_thr = m->connector == 1 ? (double)(sqrtf((float)(Wt * Ht)) / 150.f) : sqrt((double)(Wt * Ht)) / 150.0;
   memcpy(dev->pairs, m->pairs, sizeof(int) * 2 * m->n_pairs);
   memcpy(dev->mapidx, m->mapidx, sizeof(int) * 2 * m->n_pairs);
   return 0;
@@ -781,7 +784,7 @@ static int v2_prepare(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, in
   }
   if (v2_model_to_dev(m, c->cur_c, Ht, Wt, dev)) return -1;
   const size_t key = ((size_t)B << 40) ^ ((size_t)max_people << 24) ^ ((size_t)m->n_parts << 16) ^
-                     ((size_t)m->n_pairs << 8) ^ (size_t)m->max_peaks;
+                     ((size_t)m->n_pairs << 8) ^ (size_t)m->max_peaks ^ ((size_t)m->connector << 62);
   if (key != c->v2_key) {
     PH_CHECK(hipStreamSynchronize(c->stream));
     free_v2(c);
@@ -798,6 +801,8 @@ static int v2_prepare(ph_ctx* c, const ph_v2_model* m, int B, int Ht, int Wt, in
     PH_CHECK(hipMalloc(&c->v2.scores, c->v2sz.scores));
     PH_CHECK(hipMalloc(&c->v2.subsets, c->v2sz.subsets));
     PH_CHECK(hipMalloc(&c->v2.overflow, sizeof(int)));
+    PH_CHECK(hipMalloc(&c->v2.n_accept, c->v2sz.n_accept));
+    PH_CHECK(hipMalloc(&c->v2.mrg_lists, c->v2sz.mrg_lists));
     c->v2_key = key;
   }
   return 0;
@@ -902,6 +907,8 @@ int ph_decode_v2_noalloc(ph_ctx* c, const ph_v2_model* m, const float* net_out_d
   w.conn_idx = (int*)carve(sz.conn_idx);
   w.conn_score = (float*)carve(sz.conn_score);
   w.n_conn = (int*)carve(sz.n_conn);
+  w.n_accept = (int*)carve(sz.n_accept);
+  w.mrg_lists = carve(sz.mrg_lists);
   w.subsets = nullptr;  // optional output of the assembly kernel, not offered here
   if (B > PH_NOALLOC_MAX_FRAMES || off > PH_SCRATCH_BYTES) {
     ph_set_error("ph_decode_v2_noalloc: %d frames need %zu B of workspace; the static scratch holds %u B and a call "

@@ -437,7 +437,7 @@ template <bool COEF>
 __global__ __launch_bounds__(PAF_THREADS) void paf_score_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
                                                                 int Ht, int Wt, const float* __restrict__ peaks,
                                                                 PhV2Dev mdl, float* __restrict__ pair_scores,
-                                                                int n_sub) {
+                                                                int n_sub, int* __restrict__ n_accept) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int pair = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int P1 = mdl.max_peaks + 1;
@@ -487,10 +487,17 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_score_kernel(const float* __r
   __syncthreads();
 
   float* sc = pair_scores + ((size_t)b * mdl.n_pairs + pair) * mdl.max_peaks * mdl.max_peaks;
+  int accepted = 0;
   for (int p = p_begin + tid; p < p_end; p += PAF_THREADS) {
     const int i = p / nB, j = p - i * nB;  // 0-based
-    sc[p] = score_ab<COEF>(s_A + (i + 1) * 3, s_B + (j + 1) * 3, s_mx, s_my, ws, Ht, Wt, s_xt, s_yt,
-                           mdl.inter_threshold, s_kmin, mdl.close_thr, mdl.close_score);
+    const float v = score_ab<COEF>(s_A + (i + 1) * 3, s_B + (j + 1) * 3, s_mx, s_my, ws, Ht, Wt, s_xt, s_yt,
+                                   mdl.inter_threshold, s_kmin, mdl.close_thr, mdl.close_score);
+    sc[p] = v;
+    accepted += (double)v > 1e-6;
+  }
+  if (n_accept) {  // connector 1 sizes its connection list with this
+    for (int o = 32; o > 0; o >>= 1) accepted += __shfl_down(accepted, o);
+    if ((tid & 63) == 0 && accepted) atomicAdd(&n_accept[b], accepted);
   }
 }
 
@@ -844,6 +851,444 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// kernel 3': the CUDA build's assembly (upstream pafPtrIntoVector + pafVectorIntoPeopleVector; oracle:
+// paf_ptr_into_vector / paf_vector_into_people_vector).  grid (B), block MRG_THREADS.
+//
+// Upstream sorts EVERY accepted (limb, A_i, B_j) of the frame by (total, paf, limb, i, j) descending and walks the
+// list once: create / extend / add-score / merge-if-disjoint, or ignore.  Two facts make that walk parallel:
+//  * "ignore" is permanent.  People only grow (parts are never removed, merged people keep all parts), so a
+//    connection that is ignored under the current state (its person already holds that part, or the two people
+//    overlap) would be ignored at any later time too: it can be dropped as soon as it is seen to be dead.
+//  * a live connection that is the largest live key touching BOTH of its clusters (a cluster = a person, or a
+//    still unassigned peak) is reached by the sequential walk before anything else changes those clusters, so it
+//    can be applied now; all such connections of a round touch pairwise disjoint clusters and commute.
+// Rounds of (drop dead, find each cluster's best live key, apply the mutual bests) therefore reproduce the walk,
+// including the fp32 order of every person's score additions (all operations on one cluster stay in key order).
+// The walk's person order (= creation order, survivors of merges keep the lower index) is the order of the
+// founding connections' keys: people carry that key and are ranked by it at the end.
+// Live connections are kept in a compacted list in global memory once they fit it; until then the rounds scan
+// the score matrix itself and kill dead entries in place (noise maps: ~10^5 accepted pairs per frame).
+// ---------------------------------------------------------------------------
+#define MRG_THREADS 1024
+#define MRG_NONE 0xffffu
+
+struct MrgEntry {
+  unsigned total, paf, idx, cl;  // monotone keys of the two scores; idx = limb << 16 | i << 8 | j; clusters a | b << 16
+};
+
+__device__ __forceinline__ unsigned mrg_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving float -> uint
+}
+
+__global__ __launch_bounds__(MRG_THREADS) void assemble_merge_kernel(
+    const float* __restrict__ peaks, PhV2Dev mdl, float* __restrict__ pair_scores, const int* __restrict__ n_accept,
+    MrgEntry* __restrict__ lists, int list_cap, float scale, int max_people, int* __restrict__ n_people,
+    float* __restrict__ keypoints, float* __restrict__ scores, int* __restrict__ subsets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NP = mdl.n_parts, MP = mdl.max_peaks, P1 = MP + 1, NPK = NP * MP, CAP = NPK / 2 + 1;
+  // LDS carve-up (8-byte items first)
+  unsigned long long* s_best64 = (unsigned long long*)smem_raw;        // NPK: best live key of a cluster
+  unsigned long long* s_ck64 = s_best64 + NPK;                         // CAP: founding key of a person
+  unsigned* s_bestidx = (unsigned*)(s_ck64 + CAP);                     // NPK
+  unsigned* s_ckidx = s_bestidx + NPK;                                 // CAP
+  unsigned* s_mask = s_ckidx + CAP;                                    // CAP: parts a person holds
+  float* s_score = (float*)(s_mask + CAP);                             // CAP
+  float* s_pk = s_score + CAP;                                         // NP * P1 peak scores ([part][0] = count)
+  int* s_sel = (int*)(s_pk + NP * P1);                                 // CAP: entries selected this round
+  unsigned short* s_assigned = (unsigned short*)(s_sel + CAP);         // NPK: person of a peak
+  unsigned short* s_root = s_assigned + NPK + (NPK & 1);               // CAP: founding A peak = cluster id
+  unsigned char* s_rows = (unsigned char*)(s_root + CAP + (CAP & 1));  // CAP * NP: peak number per part, 0 = none
+  unsigned char* s_cnt = s_rows + (size_t)CAP * NP;                    // CAP: parts counted (0 = merged away)
+  __shared__ int s_nrows, s_nalive, s_nsel, s_moff[65], s_wcnt[MRG_THREADS / 64];
+
+  const float* pk = peaks + (size_t)b * NP * P1 * 3;
+  for (int i = tid; i < NP * P1; i += MRG_THREADS) {
+    const int part = i / P1, k = i - part * P1;
+    s_pk[i] = k == 0 ? pk[part * P1 * 3] : pk[(part * P1 + k) * 3 + 2];
+  }
+  for (int i = tid; i < NPK; i += MRG_THREADS) s_assigned[i] = MRG_NONE;
+  if (tid == 0) {
+    s_nrows = 0;
+    s_nsel = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {  // entries of limb k live at pair_scores[k][p], p < nA * nB
+    int o = 0;
+    for (int k = 0; k < mdl.n_pairs; k++) {
+      s_moff[k] = o;
+      o += pir(s_pk[mdl.pairs[2 * k] * P1]) * pir(s_pk[mdl.pairs[2 * k + 1] * P1]);
+    }
+    s_moff[mdl.n_pairs] = o;
+  }
+  __syncthreads();
+  float* mat = pair_scores + (size_t)b * mdl.n_pairs * MP * MP;
+  MrgEntry* list0 = lists + (size_t)b * 2 * list_cap;
+  MrgEntry* list1 = list0 + list_cap;
+
+  // what the walk would do with connection (limb, i, j) in the current state: 0 ignore (permanently), 1 create,
+  // 2 add B to A's person, 3 add A to B's person, 4 same person (score only), 5 merge
+  auto classify = [&](int limb, int i, int j, int* ca, int* cb) -> int {
+    const int partA = mdl.pairs[2 * limb], partB = mdl.pairs[2 * limb + 1];
+    const int sa = partA * MP + i - 1, sb = partB * MP + j - 1;
+    const unsigned pa = s_assigned[sa], pb = s_assigned[sb];
+    *ca = pa == MRG_NONE ? sa : s_root[pa];
+    *cb = pb == MRG_NONE ? sb : s_root[pb];
+    if (pa == MRG_NONE && pb == MRG_NONE) return 1;
+    if (pb == MRG_NONE) return s_rows[pa * NP + partB] == 0 ? 2 : 0;
+    if (pa == MRG_NONE) return s_rows[pb * NP + partA] == 0 ? 3 : 0;
+    if (pa == pb) return 4;
+    return (s_mask[pa] & s_mask[pb]) == 0 ? 5 : 0;
+  };
+  // matrix scan: fn(limb, i, j, paf, &mat entry) for every entry the score kernel accepted and no round killed
+  auto for_each_mat = [&](auto&& fn) {
+    for (int limb = 0; limb < mdl.n_pairs; limb++) {
+      const int n = s_moff[limb + 1] - s_moff[limb];
+      if (n == 0) continue;
+      const int nB = pir(s_pk[mdl.pairs[2 * limb + 1] * P1]);
+      float* m = mat + (size_t)limb * MP * MP;
+      for (int p = tid; p < n; p += MRG_THREADS) {
+        const float v = m[p];
+        if ((double)v > 1e-6) {
+          const int i = p / nB;
+          fn(limb, i + 1, p - i * nB + 1, v, m + p);
+        }
+      }
+    }
+  };
+  auto total_of = [&](int limb, int i, int j, float paf) -> float {
+    return (paf + 0.1f * s_pk[mdl.pairs[2 * limb] * P1 + i]) + 0.1f * s_pk[mdl.pairs[2 * limb + 1] * P1 + j];
+  };
+  // ordered append to a list: slots from one LDS counter, one atomic per wave
+  auto push = [&](MrgEntry* dst, bool want, const MrgEntry& e) {
+    const unsigned long long m = __ballot(want);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&s_nalive, __popcll(m));
+    base = __shfl(base, 0);
+    if (want) dst[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+  };
+
+  bool in_list = n_accept[b] <= list_cap;  // (block-uniform)
+  MrgEntry* cur = list0;
+  MrgEntry* nxt = list1;
+  int n_cur = 0;
+  if (in_list) {  // the accepted pairs fit the list: build it once, the matrix is not touched again
+    if (tid == 0) s_nalive = 0;
+    __syncthreads();
+    for (int limb = 0; limb < mdl.n_pairs; limb++) {
+      const int n = s_moff[limb + 1] - s_moff[limb];
+      if (n == 0) continue;
+      const int nB = pir(s_pk[mdl.pairs[2 * limb + 1] * P1]);
+      const float* m = mat + (size_t)limb * MP * MP;
+      for (int p0 = 0; p0 < n; p0 += MRG_THREADS) {
+        const int p = p0 + tid;
+        const float v = p < n ? m[p] : 0.f;
+        const bool want = (double)v > 1e-6;
+        MrgEntry e = {0u, 0u, 0u, 0u};
+        if (want) {
+          const int i = p / nB + 1, j = p - (i - 1) * nB + 1;
+          e.total = mrg_key(total_of(limb, i, j, v));
+          e.paf = mrg_key(v);
+          e.idx = ((unsigned)limb << 16) | ((unsigned)i << 8) | (unsigned)j;
+        }
+        push(cur, want, e);
+      }
+    }
+    __syncthreads();
+    n_cur = s_nalive;
+  }
+
+  for (;;) {
+    // ---- pass 1: drop dead connections, best (total, paf) key per cluster
+    for (int i = tid; i < NPK; i += MRG_THREADS) {
+      s_best64[i] = 0ull;
+      s_bestidx[i] = 0u;
+    }
+    if (tid == 0) s_nalive = 0;
+    __syncthreads();
+    if (in_list) {
+      for (int q0 = 0; q0 < n_cur; q0 += MRG_THREADS) {
+        const int q = q0 + tid;
+        MrgEntry e = {0u, 0u, 0u, 0u};
+        bool live = false;
+        if (q < n_cur) {
+          e = cur[q];
+          if (e.idx != 0xffffffffu) {  // (applied connections are consumed)
+            int ca, cb;
+            live = classify((int)(e.idx >> 16), (int)((e.idx >> 8) & 0xff), (int)(e.idx & 0xff), &ca, &cb) != 0;
+            if (live) {
+              e.cl = (unsigned)ca | ((unsigned)cb << 16);
+              const unsigned long long key = ((unsigned long long)e.total << 32) | e.paf;
+              atomicMax(&s_best64[ca], key);
+              if (cb != ca) atomicMax(&s_best64[cb], key);
+            }
+          }
+        }
+        push(nxt, live, e);
+      }
+    } else {
+      int live_n = 0;
+      for_each_mat([&](int limb, int i, int j, float paf, float* at) {
+        int ca, cb;
+        if (classify(limb, i, j, &ca, &cb) == 0) {
+          *at = 0.f;  // dead for good
+          return;
+        }
+        const unsigned long long key = ((unsigned long long)mrg_key(total_of(limb, i, j, paf)) << 32) | mrg_key(paf);
+        atomicMax(&s_best64[ca], key);
+        if (cb != ca) atomicMax(&s_best64[cb], key);
+        live_n++;
+      });
+      for (int o = 32; o > 0; o >>= 1) live_n += __shfl_down(live_n, o);
+      if (lane == 0 && live_n) atomicAdd(&s_nalive, live_n);
+    }
+    __syncthreads();
+    const int n_alive = s_nalive;
+    if (n_alive == 0) break;
+    if (in_list) {
+      MrgEntry* t = cur;
+      cur = nxt;
+      nxt = t;
+      n_cur = n_alive;
+    }
+    // ---- pass 2: among a cluster's best keys, the largest (limb, i, j)
+    if (in_list) {
+      for (int q = tid; q < n_cur; q += MRG_THREADS) {
+        const MrgEntry e = cur[q];
+        const unsigned long long key = ((unsigned long long)e.total << 32) | e.paf;
+        const int ca = e.cl & 0xffff, cb = e.cl >> 16;
+        if (s_best64[ca] == key) atomicMax(&s_bestidx[ca], e.idx);
+        if (cb != ca && s_best64[cb] == key) atomicMax(&s_bestidx[cb], e.idx);
+      }
+    } else {
+      for_each_mat([&](int limb, int i, int j, float paf, float* at) {
+        int ca, cb;
+        classify(limb, i, j, &ca, &cb);
+        const unsigned long long key = ((unsigned long long)mrg_key(total_of(limb, i, j, paf)) << 32) | mrg_key(paf);
+        const unsigned idx = ((unsigned)limb << 16) | ((unsigned)i << 8) | (unsigned)j;
+        if (s_best64[ca] == key) atomicMax(&s_bestidx[ca], idx);
+        if (cb != ca && s_best64[cb] == key) atomicMax(&s_bestidx[cb], idx);
+      });
+    }
+    __syncthreads();
+    // ---- pass 3: connections that are the best of both their clusters
+    if (in_list) {
+      for (int q = tid; q < n_cur; q += MRG_THREADS) {
+        const MrgEntry e = cur[q];
+        const unsigned long long key = ((unsigned long long)e.total << 32) | e.paf;
+        const int ca = e.cl & 0xffff, cb = e.cl >> 16;
+        if (s_best64[ca] == key && s_bestidx[ca] == e.idx && s_best64[cb] == key && s_bestidx[cb] == e.idx)
+          s_sel[atomicAdd(&s_nsel, 1)] = q;
+      }
+    } else {
+      for_each_mat([&](int limb, int i, int j, float paf, float* at) {
+        int ca, cb;
+        classify(limb, i, j, &ca, &cb);
+        const unsigned long long key = ((unsigned long long)mrg_key(total_of(limb, i, j, paf)) << 32) | mrg_key(paf);
+        const unsigned idx = ((unsigned)limb << 16) | ((unsigned)i << 8) | (unsigned)j;
+        if (s_best64[ca] == key && s_bestidx[ca] == idx && s_best64[cb] == key && s_bestidx[cb] == idx)
+          s_sel[atomicAdd(&s_nsel, 1)] = (int)(at - mat);
+      });
+    }
+    __syncthreads();
+    // ---- apply (disjoint clusters: no two selected connections touch the same person or peak)
+    const int nsel = s_nsel;
+    for (int t = tid; t < nsel; t += MRG_THREADS) {
+      int limb, i, j;
+      float paf;
+      unsigned tkey, pkey;
+      if (in_list) {
+        const MrgEntry e = cur[s_sel[t]];
+        limb = (int)(e.idx >> 16);
+        i = (int)((e.idx >> 8) & 0xff);
+        j = (int)(e.idx & 0xff);
+        pkey = e.paf;
+        tkey = e.total;
+        paf = __uint_as_float((pkey & 0x80000000u) ? (pkey & 0x7fffffffu) : ~pkey);
+        cur[s_sel[t]].idx = 0xffffffffu;
+      } else {
+        const int off = s_sel[t];
+        limb = off / (MP * MP);
+        const int p = off - limb * MP * MP, nB = pir(s_pk[mdl.pairs[2 * limb + 1] * P1]);
+        i = p / nB + 1;
+        j = p - (i - 1) * nB + 1;
+        paf = mat[off];
+        pkey = mrg_key(paf);
+        tkey = mrg_key(total_of(limb, i, j, paf));
+        mat[off] = 0.f;
+      }
+      const int partA = mdl.pairs[2 * limb], partB = mdl.pairs[2 * limb + 1];
+      const int sa = partA * MP + i - 1, sb = partB * MP + j - 1;
+      int ca, cb;
+      const int what = classify(limb, i, j, &ca, &cb);
+      const float scA = s_pk[partA * P1 + i], scB = s_pk[partB * P1 + j];
+      if (what == 1) {
+        const int r = atomicAdd(&s_nrows, 1);  // (any free row: the final order comes from the founding keys)
+        for (int k = 0; k < NP; k++) s_rows[r * NP + k] = 0;
+        s_rows[r * NP + partA] = (unsigned char)i;
+        s_rows[r * NP + partB] = (unsigned char)j;
+        s_mask[r] = (1u << partA) | (1u << partB);
+        s_cnt[r] = 2;
+        s_score[r] = (scA + scB) + paf;
+        s_ck64[r] = ((unsigned long long)tkey << 32) | pkey;
+        s_ckidx[r] = ((unsigned)limb << 16) | ((unsigned)i << 8) | (unsigned)j;
+        s_root[r] = (unsigned short)sa;
+        s_assigned[sa] = (unsigned short)r;
+        s_assigned[sb] = (unsigned short)r;
+      } else if (what == 2 || what == 3) {
+        const int r = what == 2 ? s_assigned[sa] : s_assigned[sb];
+        const int part2 = what == 2 ? partB : partA, n2 = what == 2 ? j : i;
+        s_rows[r * NP + part2] = (unsigned char)n2;
+        s_mask[r] |= 1u << part2;
+        s_cnt[r] = s_cnt[r] + 1;
+        s_score[r] = s_score[r] + ((what == 2 ? scB : scA) + paf);
+        s_assigned[what == 2 ? sb : sa] = (unsigned short)r;
+      } else if (what == 4) {
+        const int r = s_assigned[sa];
+        s_score[r] = s_score[r] + paf;
+      } else if (what == 5) {
+        int r1 = s_assigned[sa], r2 = s_assigned[sb];
+        // the walk keeps the lower index = the person founded earlier = the larger founding key
+        const bool first_is_1 = s_ck64[r1] > s_ck64[r2] || (s_ck64[r1] == s_ck64[r2] && s_ckidx[r1] > s_ckidx[r2]);
+        if (!first_is_1) {
+          const int t2 = r1;
+          r1 = r2;
+          r2 = t2;
+        }
+        for (int k = 0; k < NP; k++) {
+          const int n2 = s_rows[r2 * NP + k];
+          if (n2 != 0) {
+            s_rows[r1 * NP + k] = (unsigned char)n2;
+            s_assigned[k * MP + n2 - 1] = (unsigned short)r1;
+          }
+        }
+        s_mask[r1] |= s_mask[r2];
+        s_cnt[r1] = s_cnt[r1] + s_cnt[r2];
+        s_score[r1] = s_score[r1] + (s_score[r2] + paf);
+        s_cnt[r2] = 0;
+        s_mask[r2] = 0;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_nsel = 0;
+    // the live connections fit the list now: compact them out of the matrix once and go on from the list
+    if (!in_list && n_alive <= list_cap) {
+      if (tid == 0) s_nalive = 0;
+      __syncthreads();
+      for (int limb = 0; limb < mdl.n_pairs; limb++) {
+        const int n = s_moff[limb + 1] - s_moff[limb];
+        if (n == 0) continue;
+        const int nB = pir(s_pk[mdl.pairs[2 * limb + 1] * P1]);
+        const float* m = mat + (size_t)limb * MP * MP;
+        for (int p0 = 0; p0 < n; p0 += MRG_THREADS) {
+          const int p = p0 + tid;
+          const float v = p < n ? m[p] : 0.f;
+          const bool want = (double)v > 1e-6;
+          MrgEntry e = {0u, 0u, 0u, 0u};
+          if (want) {
+            const int i = p / nB + 1, j = p - (i - 1) * nB + 1;
+            e.total = mrg_key(total_of(limb, i, j, v));
+            e.paf = mrg_key(v);
+            e.idx = ((unsigned)limb << 16) | ((unsigned)i << 8) | (unsigned)j;
+          }
+          push(cur, want, e);
+        }
+      }
+      __syncthreads();
+      n_cur = s_nalive;
+      in_list = true;
+    }
+    __syncthreads();
+  }
+
+  // ---- person order of the walk: descending founding key among the people that were not merged away
+  const int n = s_nrows;
+  unsigned short* s_order = (unsigned short*)s_best64;  // (the round tables are free now)
+  int* s_total = &s_nalive;
+  __syncthreads();
+  for (int r = tid; r < n; r += MRG_THREADS) {
+    if (s_cnt[r] == 0) continue;
+    const unsigned long long k64 = s_ck64[r];
+    const unsigned kid = s_ckidx[r];
+    int rank = 0;
+    for (int q = 0; q < n; q++)
+      rank += s_cnt[q] != 0 && (s_ck64[q] > k64 || (s_ck64[q] == k64 && s_ckidx[q] > kid));
+    s_order[rank] = (unsigned short)r;
+  }
+  if (tid == 0) {
+    int live = 0;
+    for (int r = 0; r < n; r++) live += s_cnt[r] != 0;
+    s_nsel = live;
+  }
+  __syncthreads();
+  const int n_live = s_nsel;
+  // ---- removePeopleBelowThresholds + peopleVectorToPeopleArray (as in assemble_kernel)
+  const float denom = (float)(NP + mdl.n_pairs);
+  const int off = 3 * P1;
+  int total = 0;
+  for (int pass = 0; pass < 2; pass++) {  // pass 1 = maximizePositives retry
+    total = 0;
+    for (int q0 = 0; q0 < n_live; q0 += MRG_THREADS) {
+      const int q = q0 + tid;
+      bool ok = false;
+      int r = 0;
+      if (q < n_live) {
+        r = s_order[q];
+        int counter = s_cnt[r];
+        if (pass == 0 && NP == 25) {
+          int feet = 0;
+          for (int k = 19; k < 25; k++) feet += s_rows[r * NP + k] > 0;
+          counter -= feet;
+        }
+        ok = counter >= mdl.min_subset_cnt && s_score[r] / (float)counter >= mdl.min_subset_score;
+      }
+      const unsigned long long m = __ballot(ok);
+      if (lane == 0) s_wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int before = 0, all = 0;
+      for (int w = 0; w < MRG_THREADS / 64; w++) {
+        before += w < wave ? s_wcnt[w] : 0;
+        all += s_wcnt[w];
+      }
+      if (ok) {
+        const int o = total + before + __popcll(m & ((1ull << lane) - 1ull));
+        if (o < max_people) {
+          float* kp = keypoints + ((size_t)b * max_people + o) * NP * 3;
+          for (int k = 0; k < NP; k++) {
+            const int pn = s_rows[r * NP + k];
+            if (pn > 0) {
+              const float* src = pk + ((size_t)k * P1 + pn) * 3;
+              kp[k * 3 + 0] = src[0] * scale;
+              kp[k * 3 + 1] = src[1] * scale;
+              kp[k * 3 + 2] = src[2];
+            } else {
+              kp[k * 3 + 0] = 0.f;
+              kp[k * 3 + 1] = 0.f;
+              kp[k * 3 + 2] = 0.f;
+            }
+          }
+          scores[(size_t)b * max_people + o] = s_score[r] / denom;
+          if (subsets) {
+            int* sb = subsets + ((size_t)b * max_people + o) * (NP + 1);
+            for (int k = 0; k < NP; k++) {
+              const int pn = s_rows[r * NP + k];
+              sb[k] = pn > 0 ? k * off + pn * 3 + 2 : 0;
+            }
+            sb[NP] = s_cnt[r];
+          }
+        }
+      }
+      total += all;
+      __syncthreads();
+    }
+    if (total > 0) break;
+  }
+  if (tid == 0) n_people[b] = total;
+  (void)s_total;
+}
+
+// ---------------------------------------------------------------------------
 // optional: materialise upsampled maps (datum.poseHeatMaps export only -- the
 // decode itself never needs them).  grid-stride over [nc][Ht][Wt] of one frame.
 // ---------------------------------------------------------------------------
@@ -928,6 +1373,8 @@ int ph_v2_workspace_sizes(const PhV2Dev& m, int B, int max_people, PhV2Sizes* s)
   s->subsets = (size_t)B * max_people * (m.n_parts + 1) * sizeof(int);
   s->nms_keys = (size_t)B * m.n_parts * PH_V2_NMS_SPLIT * m.max_peaks * sizeof(int);
   s->nms_cnt = (size_t)B * m.n_parts * PH_V2_NMS_SPLIT * sizeof(int);
+  s->n_accept = (size_t)B * sizeof(int);
+  s->mrg_lists = m.connector == 1 ? (size_t)B * 2 * PH_V2_MRG_LIST_CAP * sizeof(MrgEntry) : 256;
   return 0;
 }
 
@@ -986,6 +1433,17 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   const int row_cap = PH_V2_ROW_CAP;
   const size_t lds3 = ((size_t)row_cap + 2 * (size_t)m.n_parts * (m.max_peaks + 1) + 3 * (size_t)m.max_peaks) * 4 +
                       (size_t)2 * (m.max_peaks + 2) * 2 + (size_t)row_cap * (m.n_parts + 1) * 2;
+  const size_t npk = (size_t)m.n_parts * m.max_peaks, mcap = npk / 2 + 1;
+  const size_t lds3m = 8 * (npk + mcap) + 4 * (npk + 4 * mcap + (size_t)m.n_parts * (m.max_peaks + 1)) +
+                       2 * (npk + 1 + mcap + 1) + mcap * m.n_parts + mcap + 64;
+  if (m.connector == 1 && (m.max_peaks > 255 || npk >= 65535 || lds3m > lim)) {
+    ph_set_error("decode_v2: connector 1 needs max_peaks <= 255 and %zu B of LDS (have %zu)", lds3m, lim);
+    return -1;
+  }
+  if (m.connector != 0 && m.connector != 1) {
+    ph_set_error("decode_v2: connector %d (0 = createPeopleVector, 1 = pafVectorIntoPeopleVector)", m.connector);
+    return -1;
+  }
   if (lds1 > lim || lds1b > lim || lds2 > lim || lds2g > lim || lds3 > lim || hs > 65535 || ws > 65535) {
     ph_set_error("decode_v2: LDS budget exceeded (%zu/%zu/%zu B) for net output %dx%d target %dx%d", lds1, lds2,
                  lds3, hs, ws, Ht, Wt);
@@ -993,6 +1451,7 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   }
   static int attr[4][PH_MAX_DEVICES];
   static int attr_c[5][PH_MAX_DEVICES];
+  static int attr_m[PH_MAX_DEVICES];
   if (ph_ensure_lds((const void*)nms_detect_kernel, (int)lim, attr[0]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<1>, (int)lim, attr_c[0]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<2>, (int)lim, attr_c[1]) ||
@@ -1001,12 +1460,14 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
       ph_ensure_lds((const void*)paf_score_kernel<false>, (int)lim, attr[2]) ||
       ph_ensure_lds((const void*)paf_score_kernel<true>, (int)lim, attr_c[3]) ||
       ph_ensure_lds((const void*)paf_greedy_kernel, (int)lim, attr_c[4]) ||
-      ph_ensure_lds((const void*)assemble_kernel, (int)lim, attr[3]))
+      ph_ensure_lds((const void*)assemble_kernel, (int)lim, attr[3]) ||
+      ph_ensure_lds((const void*)assemble_merge_kernel, (int)lim, attr_m))
     return -1;
   PhV2Sizes sz;
   ph_v2_workspace_sizes(m, B, max_people, &sz);
   PH_CHECK(hipMemsetAsync(w.peaks, 0, sz.peaks, stream));
   PH_CHECK(hipMemsetAsync(w.overflow, 0, sizeof(int), stream));
+  if (m.connector == 1) PH_CHECK(hipMemsetAsync(w.n_accept, 0, sz.n_accept, stream));
   if (ev) PH_CHECK(hipEventRecord(ev[0], stream));
   if (nms_bands) {
     hipLaunchKernelGGL(nms_detect_kernel, dim3(m.n_parts, B, n_split), dim3(NMS_TX, NMS_TY), lds1, stream, net_out, C,
@@ -1024,13 +1485,22 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(paf_coef ? paf_score_kernel<true> : paf_score_kernel<false>, dim3(m.n_pairs, B, paf_sub),
                      dim3(PAF_THREADS), lds2, stream, net_out, C, hs, ws, Ht, Wt, (const float*)w.peaks, m,
-                     w.pair_scores, paf_sub);
-  hipLaunchKernelGGL(paf_greedy_kernel, dim3(m.n_pairs, B), dim3(PAF_THREADS), lds2g, stream, (const float*)w.peaks, m,
-                     (const float*)w.pair_scores, w.conn_idx, w.conn_score, w.n_conn);
-  if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
-  hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(64), lds3, stream, (const float*)w.peaks, m,
-                     (const int*)w.conn_idx, (const float*)w.conn_score, (const int*)w.n_conn, scale, max_people,
-                     row_cap, w.n_people, w.keypoints, w.scores, w.subsets, w.overflow);
+                     w.pair_scores, paf_sub, m.connector == 1 ? w.n_accept : (int*)nullptr);
+  if (m.connector == 0) {
+    hipLaunchKernelGGL(paf_greedy_kernel, dim3(m.n_pairs, B), dim3(PAF_THREADS), lds2g, stream, (const float*)w.peaks,
+                       m, (const float*)w.pair_scores, w.conn_idx, w.conn_score, w.n_conn);
+    if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
+    hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(64), lds3, stream, (const float*)w.peaks, m,
+                       (const int*)w.conn_idx, (const float*)w.conn_score, (const int*)w.n_conn, scale, max_people,
+                       row_cap, w.n_people, w.keypoints, w.scores, w.subsets, w.overflow);
+  } else {
+    // CUDA-build connector: no per-limb matching; one globally ordered walk over all accepted pairs
+    PH_CHECK(hipMemsetAsync(w.n_conn, 0, sz.n_conn, stream));  // (ph_decode_v2_connections then reports none)
+    if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
+    hipLaunchKernelGGL(assemble_merge_kernel, dim3(B), dim3(MRG_THREADS), lds3m, stream, (const float*)w.peaks, m,
+                       w.pair_scores, (const int*)w.n_accept, (MrgEntry*)w.mrg_lists, PH_V2_MRG_LIST_CAP, scale,
+                       max_people, w.n_people, w.keypoints, w.scores, w.subsets);
+  }
   if (ev) PH_CHECK(hipEventRecord(ev[3], stream));
   PH_CHECK(hipGetLastError());
   return 0;

@@ -43,7 +43,7 @@ class PhV2Model(C.Structure):
                 ("nms_threshold", C.c_float), ("inter_threshold", C.c_float),
                 ("inter_min_above_threshold", C.c_float),
                 ("min_subset_score", C.c_float),
-                ("pairs", C.c_int * 128), ("mapidx", C.c_int * 128)]
+                ("pairs", C.c_int * 128), ("mapidx", C.c_int * 128), ("connector", C.c_int)]
 
 
 class PhV1Model(C.Structure):
@@ -155,6 +155,7 @@ def v2_model_struct(model):
     m.inter_threshold = model.inter_threshold
     m.inter_min_above_threshold = model.inter_min_above_threshold
     m.min_subset_score = model.min_subset_score
+    m.connector = int(getattr(model, "connector", 0))
     for k, (a, b) in enumerate(model.pairs):
         m.pairs[2 * k], m.pairs[2 * k + 1] = a, b
     for k, (a, b) in enumerate(model.mapidx):

@@ -191,7 +191,7 @@ class Engine:
     def decode_v2_noalloc(self, model, net_out, Ht, Wt, n_people, keypoints, scores, scale=1.0, overflow=None):
         """The allocation-free decode: net_out f32 [B,C,Hs,Ws], n_people i32 [B], keypoints f32 [B,M,J,3],
         scores f32 [B,M] (and overflow i32 [1]) are the caller's CUDA tensors; asynchronous on the engine's stream.
-        At most PH_NOALLOC_MAX_FRAMES BODY_25 frames per call (static 16 MiB workspace per GPU)."""
+        At most PH_NOALLOC_MAX_FRAMES BODY_25 frames per call (static 20 MiB workspace per GPU)."""
         ms, model = self._v2(model)
         for t in (net_out, n_people, keypoints, scores):
             if not t.is_cuda or not t.is_contiguous():

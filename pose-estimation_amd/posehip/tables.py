@@ -106,7 +106,7 @@ class PoseModelV2:
     ``getPoseDefaultNmsThreshold`` etc. with ``maximizePositives=false``.
     """
 
-    def __init__(self, name, parts, pairs, mapidx, ear_pair_indices):
+    def __init__(self, name, parts, pairs, mapidx, ear_pair_indices, connector=1):
         self.name = name
         self.parts = parts
         self.n_parts = len(parts) - 1          # without background
@@ -122,12 +122,23 @@ class PoseModelV2:
         self.inter_threshold = 0.05
         self.min_subset_cnt = 3
         self.min_subset_score = 0.4
+        # person assembly of upstream bodyPartConnector: 1 = the CUDA build's pafPtrIntoVector +
+        # pafVectorIntoPeopleVector (what the reference's Docker image runs, Dockerfile.U20:66-95), 0 = the
+        # CPU-only build's per-limb greedy + createPeopleVector
+        self.connector = connector
+
+    def with_connector(self, connector):
+        """The same model with the other upstream assembly route."""
+        return PoseModelV2(self.name, self.parts, self.pairs, self.mapidx, self.ear_pair_indices, connector)
 
 
 BODY_25 = PoseModelV2("BODY_25", BODY_25_PARTS, BODY_25_PAIRS, BODY_25_MAPIDX,
                       (18, 19))
 COCO_18 = PoseModelV2("COCO", _COCO_PARTS, COCO_18_PAIRS, COCO_18_MAPIDX,
                       (17, 18))
+
+BODY_25_CPU = BODY_25.with_connector(0)
+COCO_18_CPU = COCO_18.with_connector(0)
 
 V2_MODELS = {"BODY_25": BODY_25, "COCO": COCO_18}
 

@@ -57,11 +57,13 @@ def v2():
         kp, sc, inter = decode_v2.decode(net, model, hs * 8, ws * 8, 1.0, return_intermediates=True)
         out[tag + "_net"] = net.astype(np.float16)          # halves the fixture; decoded from this exact input
         net = out[tag + "_net"].astype(np.float32)
-        kp, sc, inter = decode_v2.decode(net, model, hs * 8, ws * 8, 1.0, return_intermediates=True)
-        out[tag + "_kp"], out[tag + "_sc"] = kp, sc
-        out[tag + "_peaks_n"] = inter["peaks"][:, 0, 0].astype(np.int32)
-        rows = inter["rows"][inter["valid"]] if len(inter["valid"]) else np.zeros((0, model.n_parts + 1), np.int32)
-        out[tag + "_rows"] = rows
+        for suffix, connector in (("", 0), ("1", 1)):     # CPU-build / CUDA-build assembly of upstream
+            kp, sc, inter = decode_v2.decode(net, model, hs * 8, ws * 8, 1.0, return_intermediates=True,
+                                             connector=connector)
+            out[tag + "_kp" + suffix], out[tag + "_sc" + suffix] = kp, sc
+            out[tag + "_peaks_n"] = inter["peaks"][:, 0, 0].astype(np.int32)
+            rows = inter["rows"][inter["valid"]] if len(inter["valid"]) else np.zeros((0, model.n_parts + 1), np.int32)
+            out[tag + "_rows" + suffix] = rows
     np.savez_compressed(os.path.join(HERE, "v2_scenes.npz"), **out)
 
 

@@ -15,15 +15,18 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 
 @pytest.mark.parametrize("tag,model", [("b25_p3", BODY_25), ("b25_p0", BODY_25), ("b25_sq_p2", BODY_25),
                                        ("coco_p4", COCO_18)])
-def test_golden_v2(engine, tag, model):
+@pytest.mark.parametrize("connector", [0, 1])
+def test_golden_v2(engine, tag, model, connector):
     g = np.load(os.path.join(G, "v2_scenes.npz"))
+    sfx = "1" if connector else ""
     net = g[tag + "_net"].astype(np.float32)
     engine.set_net_out(net[None])
-    res, ex = engine.decode_v2(model, 1, net.shape[1] * 8, net.shape[2] * 8, want_peaks=True, want_subsets=True)
-    np.testing.assert_array_equal(res[0][0], g[tag + "_kp"])
-    np.testing.assert_array_equal(res[0][1], g[tag + "_sc"])
+    res, ex = engine.decode_v2(model.with_connector(connector), 1, net.shape[1] * 8, net.shape[2] * 8,
+                               want_peaks=True, want_subsets=True)
+    np.testing.assert_array_equal(res[0][0], g[tag + "_kp" + sfx])
+    np.testing.assert_array_equal(res[0][1], g[tag + "_sc" + sfx])
     np.testing.assert_array_equal(ex["peaks"][0, :, 0, 0].astype(np.int32), g[tag + "_peaks_n"])
-    np.testing.assert_array_equal(ex["subsets"][0, :len(g[tag + "_rows"])], g[tag + "_rows"])
+    np.testing.assert_array_equal(ex["subsets"][0, :len(g[tag + "_rows" + sfx])], g[tag + "_rows" + sfx])
 
 
 @pytest.mark.parametrize("tag", ["p3_480", "p4_656", "p2_1080"])

@@ -11,6 +11,17 @@ from posehip.tables import BODY_25, COCO_18
 pytestmark = pytest.mark.gpu
 
 
+_VARIANTS = {}
+
+
+def _m(model, connector):
+    """The model with upstream's CPU-build (0) or CUDA-build (1) person assembly."""
+    key = (model.name, connector)
+    if key not in _VARIANTS:
+        _VARIANTS[key] = model.with_connector(connector)
+    return _VARIANTS[key]
+
+
 def _oracle(net_out, model, Ht, Wt, scale):
     from oracle import decode_v2
     return decode_v2.decode(net_out, model, Ht, Wt, scale, return_intermediates=True)
@@ -19,7 +30,7 @@ def _oracle(net_out, model, Ht, Wt, scale):
 def _check_frame(kp_o, sc_o, inter, got, extras, b, model, engine=None):
     kp_g, sc_g = got[b]
     np.testing.assert_array_equal(extras["peaks"][b], inter["peaks"])
-    if engine is not None:
+    if engine is not None and model.connector == 0:     # per-limb connection lists exist on the CPU-build route only
         n, idx, cs = engine.decode_v2_connections(model, len(got))
         for k, conns in enumerate(inter["connections"]):
             assert n[b, k] == len(conns), (k, n[b, k], len(conns))
@@ -39,7 +50,9 @@ def _check_frame(kp_o, sc_o, inter, got, extras, b, model, engine=None):
     (COCO_18, 46, 82, [4]),
     (BODY_25, 23, 31, [2]),
 ])
-def test_decode_matches_oracle(engine, model, hs, ws, people):
+@pytest.mark.parametrize("connector", [0, 1])
+def test_decode_matches_oracle(engine, model, hs, ws, people, connector):
+    model = _m(model, connector)
     frames = np.stack([synth.synth_net_output(100 + i, p, model, hs, ws) for i, p in enumerate(people)])
     engine.set_net_out(frames)
     Ht, Wt = hs * 8, ws * 8
@@ -53,7 +66,9 @@ def test_decode_matches_oracle(engine, model, hs, ws, people):
         assert found > 0                         # the scenes do produce skeletons
 
 
-def test_crowded_and_truncation(engine):
+@pytest.mark.parametrize("connector", [0, 1])
+def test_crowded_and_truncation(engine, connector):
+    BODY_25 = _m(globals()["BODY_25"], connector)
     # 20 people: stresses ordered compaction; plus a noise frame that overflows 127 peaks/part
     rng = np.random.default_rng(5)
     crowded = synth.synth_net_output(7, 20, BODY_25, 46, 82)
@@ -73,7 +88,9 @@ def test_crowded_and_truncation(engine):
     (14, 260),    # 112 x 2080 target: four column groups per wave
     (92, 164),    # 736 x 1312 target: PAF planes too large for coefficient tables -> raw planes in LDS
 ])
-def test_wide_targets(engine, hs, ws):
+@pytest.mark.parametrize("connector", [0, 1])
+def test_wide_targets(engine, hs, ws, connector):
+    BODY_25 = _m(globals()["BODY_25"], connector)
     f = synth.synth_net_output(11, 3, BODY_25, hs, ws)[None]
     engine.set_net_out(f)
     got, extras = engine.decode_v2(BODY_25, 1, hs * 8, ws * 8, want_peaks=True, want_subsets=True)
@@ -83,7 +100,9 @@ def test_wide_targets(engine, hs, ws):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_random_sizes_and_ratios(engine, seed):
+@pytest.mark.parametrize("connector", [0, 1])
+def test_random_sizes_and_ratios(engine, seed, connector):
+    BODY_25 = _m(globals()["BODY_25"], connector)
     # non-integer upsampling ratios (runs of rows with equal vertical taps of uneven length), odd sizes, stripes that
     # end inside a band, widths around the 62-column groups of the NMS kernel
     rng = np.random.default_rng(900 + seed)
@@ -110,8 +129,10 @@ def test_empty_and_flat_maps(engine):
     assert got[0][0].shape == (0, 25, 3) and got[0][1].shape == (0,)
 
 
-def test_non_x8_target_and_errors(engine):
+@pytest.mark.parametrize("connector", [0, 1])
+def test_non_x8_target_and_errors(engine, connector):
     from posehip._ffi import PosehipError
+    BODY_25 = _m(globals()["BODY_25"], connector)
     f = synth.synth_net_output(3, 2, BODY_25, 46, 82)[None]
     engine.set_net_out(f)
     got, extras = engine.decode_v2(BODY_25, 1, 46 * 6, 82 * 5, want_peaks=True, want_subsets=True)
@@ -240,7 +261,7 @@ def test_person_table_overflow_is_reported_on_both_paths(engine):
     # star model: 23 limbs (k, 0) whose B side (part 0) has no peak -> every peak of the 23 other parts becomes a
     # single-part person: 23 x 127 = 2921 rows (upstream createPeopleVector, the "one side empty" branch)
     star = PoseModelV2("star", [f"p{i}" for i in range(24)] + ["Background"], [(k, 0) for k in range(1, 24)],
-                       [(2 * k, 2 * k + 1) for k in range(23)], (-1, -1))
+                       [(2 * k, 2 * k + 1) for k in range(23)], (-1, -1), connector=0)
     rng = np.random.default_rng(3)
     f = np.zeros((1, star.n_channels, 46, 82), np.float32)
     f[0, 1:24] = rng.uniform(0.1, 1.0, (23, 46, 82)).astype(np.float32)
@@ -262,3 +283,37 @@ def test_person_table_overflow_is_reported_on_both_paths(engine):
     engine.decode_v2_results(n, kp25, sc)
     engine.decode_v2_status()
     assert int(n[0]) >= 1
+
+
+def test_cuda_connector_merge_scene_and_matrix_mode(engine):
+    """connector 1 on cases built to hit its branches: (a) two partial skeletons of one person that only a late limb
+    joins (merge-if-disjoint), (b) more accepted candidate pairs than the connection list holds, so the rounds start
+    on the score matrix (noise PAFs: ~10^5 accepted pairs), (c) exact score ties (identical people)."""
+    from oracle import decode_v2
+    m1 = _m(BODY_25, 1)
+    # (a) a person whose mid-hip -> right-hip PAF is weak: upper body and right leg are founded separately and the
+    # (8, 9) connection, which comes late in the score order, merges them
+    base = synth.synth_net_output(41, 3, BODY_25, 46, 82)
+    weak = base.copy()
+    k = BODY_25.pairs.index((8, 9))
+    for ch in BODY_25.mapidx[k]:
+        weak[BODY_25.n_heat + ch] *= 0.35
+    # (b) uniform-noise heat maps + PAFs that accept most pairs
+    rng = np.random.default_rng(8)
+    noise = rng.uniform(0.0, 1.0, base.shape).astype(np.float32)
+    noise[BODY_25.n_heat:] = rng.normal(0.35, 0.25, noise[BODY_25.n_heat:].shape)
+    # (c) the same person twice, shifted by whole cells: identical peak scores and PAF sums
+    one = synth.synth_net_output(43, 1, BODY_25, 46, 40, noise=0.0)
+    twins = np.concatenate([one, one], axis=2)[:, :, :82]
+    twins = np.concatenate([twins, np.zeros((twins.shape[0], 46, 82 - twins.shape[2]), np.float32)], axis=2)
+    frames = np.stack([base, weak, noise, twins])
+    engine.set_net_out(frames)
+    got, extras = engine.decode_v2(m1, 4, 368, 656, scale=1.0, want_peaks=True, want_subsets=True, max_people=512)
+    merged = 0
+    for b in range(4):
+        kp_o, sc_o, inter = decode_v2.decode(frames[b], m1, 368, 656, 1.0, return_intermediates=True)
+        _check_frame(kp_o, sc_o, inter, got, extras, b, m1)
+        if b == 2:
+            assert len(inter["connections"]) > 16384          # the matrix-scan rounds ran
+        merged += len(inter["connections"])
+    assert len(got[1][1]) >= 1

@@ -144,12 +144,15 @@ def test_reference_predictions_file_format():
 
 @pytest.mark.parametrize("tag,model", [("b25_p3", BODY_25), ("b25_p0", BODY_25), ("b25_sq_p2", BODY_25),
                                        ("coco_p4", COCO_18)])
-def test_golden_scenes(tag, model):
+@pytest.mark.parametrize("connector", [0, 1])
+def test_golden_scenes(tag, model, connector):
     g = np.load(os.path.join(G, "v2_scenes.npz"))
+    sfx = "1" if connector else ""
     net = g[tag + "_net"].astype(np.float32)
-    kp, sc, inter = decode_v2.decode(net, model, net.shape[1] * 8, net.shape[2] * 8, 1.0, return_intermediates=True)
-    np.testing.assert_array_equal(kp, g[tag + "_kp"])
-    np.testing.assert_array_equal(sc, g[tag + "_sc"])
+    kp, sc, inter = decode_v2.decode(net, model, net.shape[1] * 8, net.shape[2] * 8, 1.0, return_intermediates=True,
+                                     connector=connector)
+    np.testing.assert_array_equal(kp, g[tag + "_kp" + sfx])
+    np.testing.assert_array_equal(sc, g[tag + "_sc" + sfx])
     np.testing.assert_array_equal(inter["peaks"][:, 0, 0].astype(np.int32), g[tag + "_peaks_n"])
 
 
@@ -204,3 +207,109 @@ def test_feature_oracle_pinned_by_the_reference_and_known_answers():
     assert f[1, 1].tolist() == [3.0, 6.0] and f[49, 24].tolist() == [2 + 1 + int(48 / (50 / 15)), 5 + 1 + int(23 / 2.5)]
     wide = features.detection_features(np.array([[10.0, 4.0, 10.5, 35.0]], np.float32), hm, (120, 80))[0]
     assert isinstance(wide, IndexError)
+
+
+# ---- the CUDA build's connector: pafPtrIntoVector + pafVectorIntoPeopleVector ----------------------
+def _peaks_with(entries):
+    """{part: [(x, y, score), ...]} -> upstream peaks array [25, 128, 3]."""
+    P1 = BODY_25.max_peaks + 1
+    peaks = np.zeros((25, P1, 3), np.float32)
+    for part, lst in entries.items():
+        peaks[part, 0, 0] = len(lst)
+        for i, v in enumerate(lst):
+            peaks[part, i + 1] = v
+    return peaks
+
+
+def _idx(part, i):
+    return part * 3 * (BODY_25.max_peaks + 1) + i * 3 + 2
+
+
+def _limb(a, b):
+    return BODY_25.pairs.index((a, b))
+
+
+def test_cuda_connector_sorted_list_and_greedy_conflict():
+    # the scene of test_sorted_greedy_and_assembly_rules: two necks, two mid-hips, PAF straight down
+    peaks = _peaks_with({1: [(100, 100, .9), (300, 100, .8)], 8: [(100, 200, .7), (200, 200, .6)]})
+    maps = np.zeros((78, 368, 656), np.float32)
+    maps[BODY_25.n_heat + BODY_25.mapidx[0][1]] = 1.0
+    conns = decode_v2.paf_ptr_into_vector(peaks, maps, BODY_25)
+    # all four pairs are accepted; order = descending paf + 0.1 * (scoreA + scoreB)
+    assert [(c[2], c[3], c[4]) for c in conns] == [(0, 1, 1), (0, 1, 2), (0, 2, 2), (0, 2, 1)]
+    f = np.float32
+    assert conns[0][0] == float(f(f(f(1.0) + f(f(0.1) * f(.9))) + f(f(0.1) * f(.7)))) and conns[0][1] == 1.0
+    rows, scores = decode_v2.paf_vector_into_people_vector(conns, peaks, BODY_25)
+    # neck0-hip0 founds person 0; neck0-hip1 is dropped (person 0 has a hip); neck1-hip1 founds person 1;
+    # neck1-hip0 joins two people that both have a neck and a hip -> no merge
+    assert rows[:, [1, 8, 25]].tolist() == [[_idx(1, 1), _idx(8, 1), 2], [_idx(1, 2), _idx(8, 2), 2]]
+    assert scores[0] == f(f(f(.9) + f(.7)) + f(1.0))
+    assert scores[1] == f(f(f(.8) + f(.6)) + f(conns[2][1]))
+
+
+def test_cuda_connector_extend_merge_and_cycle_rules():
+    f = np.float32
+    peaks = _peaks_with({p: [(10 * p + 5, 50, 0.5 + 0.01 * p), (10 * p + 5, 150, 0.4 + 0.01 * p)]
+                         for p in (0, 1, 2, 8, 9, 10, 15, 17)})
+    s = lambda part, i: peaks[part, i, 2]                                        # noqa: E731
+    # hand-made, already sorted list (total, paf, limb, iA, iB)
+    conns = [
+        (0.99, 0.90, _limb(1, 8), 1, 1),      # 1. neither assigned -> person 0 = {neck1, hip1}
+        (0.98, 0.89, _limb(9, 10), 1, 1),     # 1. person 1 = {rhip1, rknee1}
+        (0.97, 0.88, _limb(1, 8), 1, 2),      # 2. neck1 belongs to person 0, which has a mid-hip -> ignored
+        (0.96, 0.87, _limb(8, 9), 1, 1),      # 5. hip1 in person 0, rhip1 in person 1, disjoint -> merge into 0
+        (0.95, 0.86, _limb(1, 2), 1, 1),      # 2. extend person 0 with rshoulder1
+        (0.94, 0.85, _limb(1, 0), 1, 1),      #    ... nose1
+        (0.93, 0.84, _limb(0, 15), 1, 1),     #    ... reye1
+        (0.92, 0.83, _limb(15, 17), 1, 1),    #    ... rear1
+        (0.91, 0.82, _limb(2, 17), 1, 1),     # 4. rshoulder1 and rear1 both in person 0 -> score += paf only
+        (0.90, 0.81, _limb(1, 8), 2, 2),      # 1. person 2 = {neck2, hip2}
+        (0.89, 0.80, _limb(9, 10), 2, 2),     # 1. person 3 = {rhip2, rknee2}
+        (0.88, 0.79, _limb(8, 9), 2, 1),      # 5. hip2 (person 2) - rhip1 (person 0): both have a mid-hip -> no merge
+        (0.87, 0.78, _limb(8, 9), 2, 2),      # 5. person 2 + person 3 disjoint -> merge into 2
+        (0.86, 0.77, _limb(1, 2), 2, 1),      # 3.-like: rshoulder1 is person 0's, neck2 is person 2's: both have
+                                              #    a neck -> no merge
+    ]
+    rows, scores = decode_v2.paf_vector_into_people_vector(conns, peaks, BODY_25)
+    assert rows.shape == (2, 26)                       # persons 1 and 3 were merged away and removed
+    want0 = {1: 1, 8: 1, 9: 1, 10: 1, 2: 1, 0: 1, 15: 1, 17: 1}
+    for part in range(25):
+        assert rows[0, part] == (_idx(part, want0[part]) if part in want0 else 0)
+    assert rows[0, 25] == 8
+    sc = f(f(s(1, 1) + s(8, 1)) + f(.90))                                     # create
+    s1 = f(f(s(9, 1) + s(10, 1)) + f(.89))
+    sc = f(sc + f(s1 + f(.87)))                                               # merge: s0 += s1 + paf
+    for part, paf in ((2, .86), (0, .85), (15, .84), (17, .83)):
+        sc = f(sc + f(s(part, 1) + f(paf)))                                   # extend: += peak + paf
+    sc = f(sc + f(.82))                                                       # cycle: += paf
+    assert scores[0] == sc
+    assert sorted(np.nonzero(rows[1, :25])[0].tolist()) == [1, 8, 9, 10] and rows[1, 25] == 4
+    assert rows[1, 8] == _idx(8, 2) and rows[1, 9] == _idx(9, 2)
+    s2 = f(f(s(1, 2) + s(8, 2)) + f(.81))
+    s3 = f(f(s(9, 2) + s(10, 2)) + f(.80))
+    assert scores[1] == f(s2 + f(s3 + f(.78)))
+    # a B end that is assigned while A is free joins B's person (case 3)
+    rows, _ = decode_v2.paf_vector_into_people_vector(
+        [(0.9, 0.8, _limb(8, 9), 1, 1), (0.8, 0.7, _limb(1, 8), 2, 1)], peaks, BODY_25)
+    assert rows.shape[0] == 1 and rows[0, 1] == _idx(1, 2) and rows[0, 25] == 3
+    # min-parts filter on the merged result: 8 parts, score/8 >= 0.4 -> kept; the 4-part person too
+    rows, scores = decode_v2.paf_vector_into_people_vector(conns, peaks, BODY_25)
+    assert decode_v2.filter_people(rows, scores, BODY_25) == [0, 1]
+
+
+def test_cuda_connector_end_to_end_differs_from_cpu_connector_only_in_assembly():
+    from posehip import synth
+    scene = synth.synth_net_output(101, 2, BODY_25, 46, 82)
+    k0, s0, i0 = decode_v2.decode(scene, BODY_25, 368, 656, 1.0, True, connector=0)
+    k1, s1, i1 = decode_v2.decode(scene, BODY_25, 368, 656, 1.0, True, connector=1)
+    np.testing.assert_array_equal(i0["peaks"], i1["peaks"])
+    assert len(s0) == len(s1) == 2
+    # every limb the per-limb greedy keeps is also in the global list (with the same PAF score)
+    have = {(c[2], c[3], c[4]): c[1] for c in i1["connections"]}
+    off = 3 * (BODY_25.max_peaks + 1)
+    for k, lst in enumerate(i0["connections"]):
+        for ia, ib, sc in lst:
+            assert have[(k, (ia % off) // 3, (ib % off) // 3)] == float(sc)
+    # the close-keypoint threshold is float in the CUDA build, double in the CPU build
+    assert decode_v2._close_thr(656, 368, True) == float(np.float32(np.sqrt(np.float32(656 * 368))) / np.float32(150))
+    assert decode_v2._close_thr(656, 368, False) == np.sqrt(656.0 * 368.0) / 150.0
