@@ -18,14 +18,15 @@ not installed anywhere this runs:
   cv2.findContours + fillConvexPoly + minMaxLoc (utils.py:14-22)   -> blob_peaks
 
 PARITY UNPINNED against real cv2: the reference holds no golden vector for this
-path and cv2 cannot be imported.  Two stated deviations from literal
-cv2 semantics, both in ``blob_peaks``: a blob is an 8-connected component of the
-mask and its peak is the first raster arg-max of the smoothed map over the
-component (== fillConvexPoly of the outer contour for convex blobs); hole
-contours, which RETR_TREE also returns and which would add a spurious second
-keypoint for ring-shaped blobs, are not emitted.  Blob order follows
-findContours' list order for top-level contours, i.e. the reverse of the raster
-order of each blob's first pixel.
+path and cv2 cannot be imported.  ``blob_peaks`` is getKeypoints
+literally: Suzuki-Abe border following as OpenCV 4.5 contours.cpp codes it (outer
+AND hole borders, RETR_TREE list order = latest sibling first, node before its
+children), the CHAIN_APPROX_SIMPLE vertices, FillConvexPoly's outline + two-walker
+scan fill, first raster maximum of mapSmooth * mask.  ``blob_peaks_cc`` is the
+connected-component form the GPU kernels implement (8-connected component, first
+raster arg-max, reverse raster order of first pixels); the two agree on isolated and
+merged convex bumps and differ for ring blobs (extra hole keypoint) and for shapes
+fillConvexPoly under-fills -- known answers in tests/test_oracle_v1.py.
 
 np.dot(paf_interp, d_ij) (utils.py:97) is restated as a0*d0 + a1*d1 in float64
 (two products, one add, no FMA): BLAS's internal rounding is not specified.
@@ -99,8 +100,12 @@ def gaussian3(m):
     return (p[1:-1] * f32(0.5) + (p[:-2] + p[2:]) * f32(0.25)).astype(f32)
 
 
-def blob_peaks(prob_map, threshold):
-    """getKeypoints (utils.py:9-23) -> [(x, y, score f32)] in findContours order."""
+def blob_peaks_cc(prob_map, threshold):
+    """getKeypoints (utils.py:9-23) in the simplified form the GPU kernels implement: a blob = an 8-connected
+    component of the mask, its keypoint = the first raster arg-max of the smoothed map over the component, blobs in
+    reverse raster order of their first pixel.  Equal to the literal form (blob_peaks) whenever every blob is free
+    of holes and its arg-max lies inside the polygon fillConvexPoly paints -- true for isolated, roughly convex
+    bumps; see tests/test_oracle_v1.py for the ring / L-shape / merged-people cases where the two differ."""
     from scipy import ndimage
     smooth = gaussian3(prob_map)
     mask = smooth > f32(threshold)                          # fp32 compare (utils.py:11)
@@ -126,6 +131,230 @@ def blob_peaks(prob_map, threshold):
     out = []
     for l in order:
         y, x = divmod(int(best_pix[l]), W)
+        out.append((x, y, prob_map[y, x]))
+    return out
+
+
+# ---- cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE), restated from OpenCV 4.5 contours.cpp -------------
+# (cvFindNextContour_Impl / icvFetchContour: Suzuki-Abe border following on a 0/1 image with a zero frame.)
+# Direction codes: 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE (y grows downwards).
+_CODE_DX = (1, 1, 0, -1, -1, -1, 0, 1)
+_CODE_DY = (0, -1, -1, -1, 0, 1, 1, 1)
+
+
+def _fetch_contour(img, x0, y0, is_hole, nbd):
+    """icvFetchContour / icvFetchContourEx: follow the border that starts at (x0, y0) of the padded int image,
+    mark it (nbd, or -nbd where the pixel to the right was examined and found empty) and return the vertices
+    CHAIN_APPROX_SIMPLE keeps (a point is written whenever the step direction changes)."""
+    pts = []
+    s_end = s = 0 if is_hole else 4
+    while True:
+        s = (s - 1) & 7
+        i1x, i1y = x0 + _CODE_DX[s], y0 + _CODE_DY[s]
+        if img[i1y, i1x] != 0 or s == s_end:
+            break
+    if s == s_end:                                   # single pixel domain
+        img[y0, x0] = -nbd
+        pts.append((x0, y0))
+        return pts
+    i3x, i3y = x0, y0
+    ptx, pty = x0, y0
+    prev_s = s ^ 4
+    while True:
+        s_end = s
+        while s < 15:
+            s += 1
+            i4x, i4y = i3x + _CODE_DX[s & 7], i3y + _CODE_DY[s & 7]
+            if img[i4y, i4x] != 0:
+                break
+        s &= 7
+        if ((s - 1) & 0xffffffff) < (s_end & 0xffffffff):          # (unsigned)(s - 1) < (unsigned)s_end
+            img[i3y, i3x] = -nbd
+        elif img[i3y, i3x] == 1:
+            img[i3y, i3x] = nbd
+        if s != prev_s:
+            pts.append((ptx, pty))
+            prev_s = s
+        ptx += _CODE_DX[s]
+        pty += _CODE_DY[s]
+        if (i4x, i4y) == (x0, y0) and (i3x, i3y) == (i1x, i1y):
+            break
+        i3x, i3y = i4x, i4y
+        s = (s + 4) & 7
+    return pts
+
+
+def find_contours_tree(mask):
+    """-> list of int arrays [n, 2] (x, y), in the order cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)
+    returns them: outer and hole borders; a border found later is linked in FRONT of its siblings
+    (cvInsertNodeIntoTree), and cvTreeToNodeSeq walks the tree node, children, next sibling."""
+    H, W = mask.shape
+    img = np.zeros((H + 2, W + 2), np.int64)          # copyMakeBorder(1, 1, 1, 1, BORDER_CONSTANT, 0)
+    img[1:-1, 1:-1] = (mask != 0)
+    contours = []                                      # (points, is_hole, parent) in discovery order; parent -1 = frame
+    nbd = 1
+    for y in range(1, H + 1):
+        lnbd = 0                                       # id of the last border met on this row (0 = the frame)
+        row = img[y]
+        # only positions where the value changes can start a border; visit them left to right
+        x = 1
+        prev = 0
+        while x <= W + 1:
+            p = row[x]
+            if p == prev:
+                x += 1
+                continue
+            is_hole = None
+            if prev == 0 and p == 1:
+                is_hole = False
+            elif p == 0 and prev >= 1:
+                is_hole = True
+            if is_hole is not None:
+                if is_hole and prev > 1:
+                    lnbd = prev
+                # parent: the last border met, or that border's parent when it is of the same kind
+                if lnbd == 0:
+                    parent = -1
+                else:
+                    b = lnbd - 2
+                    parent = contours[b][2] if contours[b][1] == is_hole else b
+                nbd += 1
+                sx = x - 1 if is_hole else x
+                pts = _fetch_contour(img, sx, y, is_hole, nbd)
+                contours.append((np.asarray(pts, np.int64) - 1, is_hole, parent))
+                lnbd = nbd
+                p = row[x]
+            prev = p
+            if abs(prev) > 1:
+                lnbd = abs(prev)
+            x += 1
+    children = {}
+    for i, (_, _, parent) in enumerate(contours):
+        children.setdefault(parent, []).insert(0, i)   # latest first
+    out = []
+
+    def walk(node):
+        for c in children.get(node, []):
+            out.append(contours[c][0])
+            walk(c)
+    walk(-1)
+    return out
+
+
+def _trunc_div(a, b):
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b > 0) else -q
+
+
+def fill_convex_poly(shape, pts):
+    """cv2.fillConvexPoly(zeros(shape), pts, 1) with the default lineType 8, shift 0 -- OpenCV 4.5 drawing.cpp
+    FillConvexPoly restated: the outline is drawn edge by edge (8-connected lines; the edges of a
+    CHAIN_APPROX_SIMPLE contour are straight runs), then two edge walkers start at the first vertex of minimal y,
+    one forwards and one backwards through the vertex list, and every row gets the span between them.  For a polygon
+    that is not convex the walkers still only follow those two chains: the span can miss parts of the shape."""
+    H, W = shape
+    out = np.zeros(shape, bool)
+    n = len(pts)
+    v = [(int(p[0]), int(p[1])) for p in pts]
+    XY_SHIFT, XY_ONE = 16, 1 << 16
+    # outline
+    x0, y0 = v[-1]
+    for (x1, y1) in v:
+        steps = max(abs(x1 - x0), abs(y1 - y0))
+        if steps == 0:
+            if 0 <= y0 < H and 0 <= x0 < W:
+                out[y0, x0] = True
+        else:
+            dx, dy = (x1 - x0) // steps if (x1 - x0) % steps == 0 else None, (y1 - y0) // steps if (y1 - y0) % steps == 0 else None
+            if dx is None or dy is None:
+                raise ValueError("fill_convex_poly: an edge that is not a straight 8-connected run")
+            for t in range(steps + 1):
+                xx, yy = x0 + t * dx, y0 + t * dy
+                if 0 <= yy < H and 0 <= xx < W:
+                    out[yy, xx] = True
+        x0, y0 = x1, y1
+    xmin = min(p[0] for p in v)
+    xmax = max(p[0] for p in v)
+    ymin = min(p[1] for p in v)
+    ymax = max(p[1] for p in v)
+    imin = 0
+    for i, p in enumerate(v):
+        if p[1] < v[imin][1]:
+            imin = i
+    if n < 3 or xmax < 0 or ymax < 0 or xmin >= W or ymin >= H:
+        return out
+    ymax = min(ymax, H - 1)
+    edges = n
+    e_idx = [imin, imin]
+    e_ye = [ymin, ymin]
+    e_di = [1, n - 1]
+    e_x = [-XY_ONE, -XY_ONE]
+    e_dx = [0, 0]
+    delta1 = delta2 = XY_ONE >> 1
+    y = ymin
+    while True:
+        for i in range(2):
+            if y >= e_ye[i]:
+                idx0, di = e_idx[i], e_di[i]
+                idx = idx0 + di
+                if idx >= n:
+                    idx -= n
+                while True:
+                    edges -= 1
+                    if not edges + 1 > 0:
+                        break
+                    ty = v[idx][1]
+                    if ty > y:
+                        xs = v[idx0][0] << XY_SHIFT
+                        xe = v[idx][0] << XY_SHIFT
+                        e_ye[i] = ty
+                        e_dx[i] = _trunc_div((xe - xs) * 2 + (ty - y), 2 * (ty - y))
+                        e_x[i] = xs
+                        e_idx[i] = idx
+                        break
+                    idx0 = idx
+                    idx += di
+                    if idx >= n:
+                        idx -= n
+        if edges < 0:
+            break
+        if y >= 0:
+            left, right = (1, 0) if e_x[0] > e_x[1] else (0, 1)
+            xx1 = (e_x[left] + delta1) >> XY_SHIFT
+            xx2 = (e_x[right] + delta2) >> XY_SHIFT
+            if xx2 >= 0 and xx1 < W:
+                out[y, max(xx1, 0):min(xx2, W - 1) + 1] = True
+        e_x[0] += e_dx[0]
+        e_x[1] += e_dx[1]
+        y += 1
+        if not y <= ymax:
+            break
+    return out
+
+
+def blob_peaks(prob_map, threshold):
+    """getKeypoints (utils.py:9-23), literally: GaussianBlur -> mask -> findContours(RETR_TREE,
+    CHAIN_APPROX_SIMPLE) -> per contour (outer AND hole borders, in the list order of findContours):
+    fillConvexPoly mask, minMaxLoc of mapSmooth * mask (first raster maximum), score from the unsmoothed map.
+    -> [(x, y, score f32)]"""
+    smooth = gaussian3(prob_map)
+    mask = smooth > f32(threshold)                          # fp32 compare (utils.py:11)
+    out = []
+    H, W = mask.shape
+    for cnt in find_contours_tree(mask):
+        x0, y0 = max(int(cnt[:, 0].min()), 0), max(int(cnt[:, 1].min()), 0)
+        x1, y1 = min(int(cnt[:, 0].max()), W - 1), min(int(cnt[:, 1].max()), H - 1)
+        # the painted pixels lie inside the contour's bounding box: work on that window only
+        win = fill_convex_poly((y1 - y0 + 1, x1 - x0 + 1), cnt - np.array([x0, y0]))
+        masked = np.where(win, smooth[y0:y1 + 1, x0:x1 + 1].astype(np.float64), 0.0)
+        best = float(masked.max())
+        if best > 0.0:
+            yy, xx = np.unravel_index(int(np.argmax(masked)), masked.shape)       # first raster maximum
+            x, y = int(xx) + x0, int(yy) + y0
+        else:
+            x, y = 0, 0            # minMaxLoc of a map whose maximum is the 0 outside the polygon: its first pixel
+            if best < 0.0 or not (masked == 0.0).any():
+                raise NotImplementedError("blob_peaks: maximum below zero inside the polygon")
         out.append((x, y, prob_map[y, x]))
     return out
 
@@ -225,17 +454,19 @@ def get_personwise_keypoints(valid_pairs, invalid_pairs, keypoints_list, body_pa
 
 
 def postprocess_multi(prediction, body_parts, pose_pairs, mapidx, image_width, image_height, conf_thres=0.1,
-                      return_intermediates=False):
+                      return_intermediates=False, blobs="cc"):
     """PyOpenPoseOpenCV.postprocess_multi (skeleton.py:102-154).
 
-    prediction f32 [1,C,hs,ws] -> (keypoints_list f64 [K,3], personwise list of f64 [len(body_parts)])."""
+    prediction f32 [1,C,hs,ws] -> (keypoints_list f64 [K,3], personwise list of f64 [len(body_parts)]).
+    blobs: "opencv" = getKeypoints literally (outer + hole contours, fillConvexPoly), "cc" = the connected-component
+    form the GPU kernels implement (see blob_peaks_cc for when the two agree)."""
     prediction = np.asarray(prediction, f32)
     keypoint_id = 0
     keypoints_list = np.zeros((0, 3))
     detected = []
     for i in range(len(body_parts) - 1):
         heat = resize_linear(prediction[0, i], image_width, image_height)
-        kps = blob_peaks(heat, conf_thres)
+        kps = blob_peaks(heat, conf_thres) if blobs == "opencv" else blob_peaks_cc(heat, conf_thres)
         with_id = []
         for kp in kps:
             with_id.append(kp + (keypoint_id,))

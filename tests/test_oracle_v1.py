@@ -188,3 +188,105 @@ def test_native_preprocess_oracle_known_answers():
     np.testing.assert_array_equal(blob[0, :, 2, 3], img[0, 2, 3].astype(np.float32) / 256 - 0.5)
     assert P.op_net_input_size("-1x368", 1920, 1080) == (656, 368)
     assert P.op_scale_factor(1920, 1080, 656, 368) == min(655 / 1919, 367 / 1079)
+
+
+# ---- getKeypoints literally: findContours(RETR_TREE, CHAIN_APPROX_SIMPLE) + fillConvexPoly -------------
+def test_find_contours_tree_known_answers():
+    from oracle import decode_v1 as D
+    m = np.zeros((8, 10), np.uint8)
+    m[1:4, 1:4] = 1                     # a square, found first
+    m[1:6, 5:10] = 1
+    m[2:5, 6:9] = 0                     # a ring, found second (same first row, further right)
+    cs = [c.tolist() for c in D.find_contours_tree(m)]
+    # list order: the border found LAST comes first; a hole border follows its outer border; vertices start at the
+    # border's first raster pixel and run counter-clockwise on screen (outer) / clockwise (hole); a hole border
+    # consists of FOREGROUND pixels, so its corners are cut diagonally
+    assert cs == [[[5, 1], [5, 5], [9, 5], [9, 1]],
+                  [[5, 2], [6, 1], [8, 1], [9, 2], [9, 4], [8, 5], [6, 5], [5, 4]],
+                  [[1, 1], [1, 3], [3, 3], [3, 1]]]
+    # a blob inside a hole: outer, its hole, the inner blob (single pixel = single vertex)
+    n = np.zeros((9, 9), np.uint8)
+    n[1:8, 1:8] = 1
+    n[2:7, 2:7] = 0
+    n[4, 4] = 1
+    cs = [c.tolist() for c in D.find_contours_tree(n)]
+    assert cs == [[[1, 1], [1, 7], [7, 7], [7, 1]],
+                  [[1, 2], [2, 1], [6, 1], [7, 2], [7, 6], [6, 7], [2, 7], [1, 6]],
+                  [[4, 4]]]
+    # diamond: four vertices, starts at the top
+    yy, xx = np.mgrid[0:9, 0:9]
+    d = (abs(yy - 4) + abs(xx - 4) <= 3).astype(np.uint8)
+    assert [c.tolist() for c in D.find_contours_tree(d)] == [[[4, 1], [1, 4], [4, 7], [7, 4]]]
+    # pixels touching the image border are handled (zero frame added, as cv2 does since 3.2)
+    e = np.ones((3, 4), np.uint8)
+    assert [c.tolist() for c in D.find_contours_tree(e)] == [[[0, 0], [0, 2], [3, 2], [3, 0]]]
+    assert D.find_contours_tree(np.zeros((4, 4), np.uint8)) == []
+
+
+def test_fill_convex_poly_known_answers():
+    from oracle import decode_v1 as D
+    yy, xx = np.mgrid[0:9, 0:9]
+    d = (abs(yy - 4) + abs(xx - 4) <= 3)
+    np.testing.assert_array_equal(D.fill_convex_poly(d.shape, D.find_contours_tree(d)[0]), d)     # convex: exact
+    sq = np.zeros((6, 7), bool)
+    sq[1:5, 2:6] = True
+    np.testing.assert_array_equal(D.fill_convex_poly(sq.shape, D.find_contours_tree(sq)[0]), sq)
+    # a U with 5-pixel arms: the two edge walkers follow the left arm only; of the right arm just the outline is
+    # painted, its interior is missed (the polygon is not convex)
+    u = np.zeros((18, 21), bool)
+    u[1:15, 1:6] = True
+    u[1:15, 13:18] = True
+    u[11:15, 1:18] = True
+    f = D.fill_convex_poly(u.shape, D.find_contours_tree(u)[0])
+    assert not (f & ~u).any()
+    missed = np.argwhere(u & ~f)
+    assert len(missed) == 3 * 9 and missed[:, 1].min() == 14 and missed[:, 1].max() == 16     # interior of the right arm
+    assert missed[:, 0].min() == 2 and missed[:, 0].max() == 10
+
+
+def test_get_keypoints_literal_vs_connected_components():
+    """Where the literal getKeypoints (contours + fillConvexPoly) and the connected-component form the GPU kernels
+    implement agree, and the three documented cases where they do not."""
+    from oracle import decode_v1 as D
+    f32 = np.float32
+    yy, xx = np.mgrid[0:24, 0:40].astype(f32)
+
+    def bump(x0, y0, a, s=3.0):
+        return (a * np.exp(-((xx - x0) ** 2 + (yy - y0) ** 2) / (2 * s * s))).astype(f32)
+    # isolated bumps and two MERGED people (one peanut-shaped blob): identical, one keypoint per blob
+    for m in (bump(10, 10, 0.8), np.maximum(bump(8, 12, 0.8), bump(30, 9, 0.7)),
+              np.maximum(bump(12, 12, 0.8), bump(24, 10, 0.9))):
+        assert D.blob_peaks(m, 0.1) == D.blob_peaks_cc(m, 0.1)
+    merged = D.blob_peaks(np.maximum(bump(12, 12, 0.8), bump(24, 10, 0.9)), 0.1)
+    assert [(x, y) for x, y, _ in merged] == [(24, 10)]                  # the lower person of the pair is lost (V1)
+    # ring blob: RETR_TREE also returns the hole border -> an extra keypoint on the ring's inner edge whose score
+    # is read from the UNSMOOTHED map (0 here); every later keypoint id shifts by one
+    r = np.zeros((16, 16), f32)
+    r[3:13, 3:13] = 0.5
+    r[6:10, 6:10] = 0
+    r[4, 11] = 0.9
+    assert D.blob_peaks(r, 0.1) == [(11, 4, f32(0.9)), (7, 6, f32(0.0))]
+    assert D.blob_peaks_cc(r, 0.1) == [(11, 4, f32(0.9))]
+    # U-shaped blob whose maximum sits inside the arm fillConvexPoly misses: the literal form reports the first
+    # raster maximum of what was painted instead
+    u = np.zeros((20, 22), f32)
+    u[2:16, 2:7] = 0.5
+    u[2:16, 14:19] = 0.5
+    u[12:16, 2:19] = 0.5
+    u[5, 16] = 0.9
+    assert D.blob_peaks(u, 0.1) == [(3, 3, f32(0.5))]
+    assert D.blob_peaks_cc(u, 0.1) == [(16, 5, f32(0.9))]
+
+
+@pytest.mark.parametrize("tag", ["p3_480", "p4_656", "p2_1080"])
+def test_golden_scenes_literal_blobs_equal_connected_components(tag):
+    """On the committed V1 scenes (which the GPU kernels reproduce bit for bit) the literal getKeypoints gives
+    the same keypoints in the same order as the connected-component form: GPU == literal there, transitively."""
+    import os
+    from oracle import decode_v1 as D
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "v1_scenes.npz"))
+    W, H = (int(v) for v in g[tag + "_size"])
+    net = g[tag + "_net"].astype(np.float32)
+    for part in range(18):
+        heat = D.resize_linear(net[part], W, H)
+        assert D.blob_peaks(heat, 0.1) == D.blob_peaks_cc(heat, 0.1)
