@@ -236,158 +236,173 @@ class Wrapper:
         return True
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# Batched NumPy forms of the reference's per-person helpers.  Same results as the loops at
+# native/python/skeleton.py:89-160 (the device versions are ph_pose_post / Engine.pose_post).
+# ----------------------------------------------------------------------------------------------------------------
+def torso_boxes(keypoints: np.ndarray, torso_ids=TORSO_IDS) -> np.ndarray:
+    """[M, J, 3] keypoints -> [M, 4] (u_min, v_min, u_max, v_max) over the torso joints whose score is not 0;
+    a side of zero length grows by 1, a person without any torso joint gets (0, 0, 1, 1).  The result dtype
+    follows what the reference's list-of-arrays ``np.stack`` produces: the keypoint dtype when every person has a
+    box, int64 when nobody has, float64 when the two kinds mix."""
+    t = np.asarray(keypoints)[:, list(torso_ids), :]
+    seen = t[..., 2] != 0
+    have = seen.any(axis=1)
+    big = np.finfo(t.dtype).max if t.dtype.kind == "f" else np.iinfo(t.dtype).max
+    uv = t[..., :2]
+    lo = np.where(seen[..., None], uv, big).min(axis=1)
+    hi = np.where(seen[..., None], uv, -big).max(axis=1)
+    hi = np.where(hi == lo, hi + uv.dtype.type(1), hi)
+    box = np.concatenate([lo, hi], axis=1)
+    if have.all():
+        return box
+    out = np.empty(box.shape, np.int64 if not have.any() else np.float64)
+    out[have] = box[have]
+    out[~have] = (0, 0, 1, 1)
+    return out
+
+
+def integer_boxes(boxes: np.ndarray) -> np.ndarray:
+    """Outward-rounded boxes: floor of the minima, ceil of the maxima, as Python ints (int64)."""
+    b = np.asarray(boxes)
+    return np.concatenate([np.floor(b[:, :2]), np.ceil(b[:, 2:])], axis=1).astype(int)
+
+
+def _intrinsics(intr_mat) -> Tuple[float, float, float, float]:
+    """(fx, fy, cx, cy) from a flat 3x3 list or a 3x3 array."""
+    if isinstance(intr_mat, list):
+        return intr_mat[0], intr_mat[4], intr_mat[2], intr_mat[5]
+    if isinstance(intr_mat, np.ndarray):
+        return intr_mat[0, 0], intr_mat[1, 1], intr_mat[0, 2], intr_mat[1, 2]
+    raise ValueError("Unknown intr_mat format.")
+
+
+def lift_to_3d(joints: np.ndarray, depth_img: np.ndarray, intr_mat, depth_scale: float = 1e-3,
+               patch_offset: int = 2) -> np.ndarray:
+    """[..., 3] (x, y, score) joints -> [..., 3] float64 camera-space points: mean depth of the patch
+    [y - p, y + p) x [x - p, x + p) (clipped to the image, NaNs skipped, NaN when nothing is left) back-projected
+    through the pinhole model and multiplied by depth_scale.  All joints at once: the patches are gathered with one
+    fancy index and reduced with a validity mask."""
+    fx, fy, cx, cy = _intrinsics(intr_mat)
+    H, W = depth_img.shape
+    xy = np.asarray(joints, dtype=np.float64)[..., :2].reshape(-1, 2)
+    p = int(patch_offset)
+    first = np.trunc(xy - p).astype(np.int64)                 # int(): towards zero
+    last = np.trunc(xy + p).astype(np.int64)
+    x0, y0 = np.maximum(first[:, 0], 0), np.maximum(first[:, 1], 0)
+    x1, y1 = np.minimum(last[:, 0], W), np.minimum(last[:, 1], H)
+    side = max(int(np.max(np.maximum(x1 - x0, y1 - y0), initial=0)), 1)
+    step = np.arange(side)
+    rows = y0[:, None] + step                                 # [N, side]
+    cols = x0[:, None] + step
+    inside = ((rows < y1[:, None]) & (rows >= 0))[:, :, None] & ((cols < x1[:, None]) & (cols >= 0))[:, None, :]
+    patch = depth_img[np.clip(rows, 0, H - 1)[:, :, None], np.clip(cols, 0, W - 1)[:, None, :]].astype(np.float64)
+    use = inside & ~np.isnan(patch)
+    n = use.sum(axis=(1, 2))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        z = np.where(use, patch, 0.0).sum(axis=(1, 2)) / n    # 0 / 0 = NaN: empty or all-NaN patch
+    out = np.stack([(xy[:, 0] - cx) / fx * z, (xy[:, 1] - cy) / fy * z, z], axis=1) * depth_scale
+    return out.reshape(np.asarray(joints).shape[:-1] + (3,))
+
+
+def write_people_csv(path: str, per_person: Optional[np.ndarray], scores: Optional[np.ndarray]) -> None:
+    """One text row per person: score, then the person's values flattened (``np.savetxt`` defaults, ',').  No
+    people: the file is created empty (an existing one is left as it is)."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    if per_person is None:
+        with open(path, 'a'):
+            return
+    people = len(per_person)
+    np.savetxt(path, np.column_stack([np.reshape(scores, (people, 1)), np.reshape(per_person, (people, -1))]),
+               delimiter=',')
+
+
+def strongest_people(scores: np.ndarray, limit: int, floor: float) -> np.ndarray:
+    """Indices of the `limit` highest scores in ascending score order, without those below `floor`."""
+    order = np.argsort(scores)[-limit:]
+    return order[np.asarray(scores)[order] >= floor]
+
+
 class PyOpenPoseNativeBase:
-    """Properties and utilities (``native/python/skeleton.py:17-370``)."""
+    """Result properties and utilities of the native estimator (interface of
+    ``native/python/skeleton.py:17-370``; the bodies are this package's own batched forms above)."""
+
+    _LAZY = ("_pose_heatmaps", "_pose_keypoints_3d", "_pose_bounding_box", "_pose_bounding_box_int")
 
     def __init__(self, skel_thres: float = 0.0, max_true_body: int = 2, patch_offset: int = 2) -> None:
         super().__init__()
-        self.skel_thres = skel_thres
-        self.max_true_body = max_true_body
-        self.patch_offset = patch_offset
+        self.skel_thres, self.max_true_body, self.patch_offset = skel_thres, max_true_body, patch_offset
         self.datum = Datum()
-        self._pose_empty = False
-        self._pose_heatmaps = None
-        self._pose_keypoints_3d = None
-        self._pose_bounding_box = None
-        self._pose_bounding_box_int = None
-        self.reset()
+        PyOpenPoseNativeBase.reset(self)
 
     def reset(self) -> None:
+        """Forget everything derived from the last frame."""
         self._pose_empty = False
-        self._pose_heatmaps = None
-        self._pose_keypoints_3d = None
-        self._pose_bounding_box = None
-        self._pose_bounding_box_int = None
-        return
+        for name in self._LAZY:
+            setattr(self, name, None)
 
-    @property
-    def opencv_image(self) -> np.ndarray:
-        return self.datum.cvOutputData
+    # ---- straight views of the datum
+    opencv_image = property(lambda self: self.datum.cvOutputData)
+    pose_empty = property(lambda self: self._pose_empty)
+    pose_scores = property(lambda self: self.datum.poseScores)
+    pose_keypoints = property(lambda self: self.datum.poseKeypoints)
+    pose_keypoints_3d = property(lambda self: self._pose_keypoints_3d)
 
-    @property
-    def pose_empty(self):
-        return self._pose_empty
-
-    @property
-    def pose_scores(self) -> Optional[np.ndarray]:
-        return self.datum.poseScores
-
+    # ---- derived, computed once per frame
     @property
     def pose_heatmaps(self) -> Optional[np.ndarray]:
-        # [op_h, op_w, C]; zeros [h, w, J] when heat maps were not requested (:64-76)
+        """Exported heat maps, channels last [h, w, C]; zeros [net_h, net_w, J] when none were requested."""
         if self._pose_heatmaps is None:
-            if self.datum.poseHeatMaps is None:
-                j = self.datum.poseKeypoints.shape[1]
-                w = self.datum.netInputSizes[0].x
-                h = self.datum.netInputSizes[0].y
-                self._pose_heatmaps = np.zeros((h, w, j))
+            d = self.datum
+            if d.poseHeatMaps is not None:
+                self._pose_heatmaps = np.moveaxis(d.poseHeatMaps, 0, -1)
             else:
-                self._pose_heatmaps = np.moveaxis(self.datum.poseHeatMaps, 0, -1)
+                size = d.netInputSizes[0]
+                self._pose_heatmaps = np.zeros((size.y, size.x, d.poseKeypoints.shape[1]))
         return self._pose_heatmaps
 
     @property
-    def pose_keypoints(self) -> Optional[np.ndarray]:
-        return self.datum.poseKeypoints
-
-    @property
-    def pose_keypoints_3d(self) -> Optional[np.ndarray]:
-        return self._pose_keypoints_3d
-
-    @property
     def pose_bounding_box(self) -> Optional[np.ndarray]:
-        # torso box over TORSO_IDS joints with score != 0 (:89-113)
         if self._pose_empty:
             return None
         if self._pose_bounding_box is None:
-            bb = []
-            for pose_keypoints in self.pose_keypoints:
-                u = pose_keypoints[TORSO_IDS, 0]
-                v = pose_keypoints[TORSO_IDS, 1]
-                s = pose_keypoints[TORSO_IDS, 2]
-                if (s != 0).any():
-                    u_min = u[s != 0].min()
-                    u_max = u[s != 0].max()
-                    v_min = v[s != 0].min()
-                    v_max = v[s != 0].max()
-                    if u_min == u_max:
-                        u_max += 1
-                    if v_min == v_max:
-                        v_max += 1
-                else:
-                    u_min = v_min = 0
-                    u_max = v_max = 1
-                bb.append(np.asarray([u_min, v_min, u_max, v_max]))
-            self._pose_bounding_box = np.stack(bb)
+            self._pose_bounding_box = torso_boxes(self.pose_keypoints, TORSO_IDS)
         return self._pose_bounding_box
 
     @property
     def pose_bounding_box_int(self) -> Optional[np.ndarray]:
         if self._pose_empty:
             return None
-        if self._pose_bounding_box_int is None:
-            _bb = self.pose_bounding_box
-            if _bb is not None:
-                u_min = np.floor(_bb[:, 0]).astype(int)
-                v_min = np.floor(_bb[:, 1]).astype(int)
-                u_max = np.ceil(_bb[:, 2]).astype(int)
-                v_max = np.ceil(_bb[:, 3]).astype(int)
-                self._pose_bounding_box_int = np.stack([u_min, v_min, u_max, v_max], axis=1)
+        if self._pose_bounding_box_int is None and self.pose_bounding_box is not None:
+            self._pose_bounding_box_int = integer_boxes(self.pose_bounding_box)
         return self._pose_bounding_box_int
 
+    # ---- 3-D
     @staticmethod
     def get_3d_skeleton(skeleton: np.ndarray, depth_img: np.ndarray, intr_mat: Union[list, np.ndarray],
                         depth_scale: float = 1e-3, patch_offset: int = 2) -> np.ndarray:
-        # depth-patch mean + pinhole back-projection (:130-160)
-        if isinstance(intr_mat, list):
-            fx, fy, cx, cy = intr_mat[0], intr_mat[4], intr_mat[2], intr_mat[5]
-        elif isinstance(intr_mat, np.ndarray):
-            fx, fy, cx, cy = intr_mat[0, 0], intr_mat[1, 1], intr_mat[0, 2], intr_mat[1, 2]
-        else:
-            raise ValueError("Unknown intr_mat format.")
-        H, W = depth_img.shape
-        joints3d = []
-        for x, y, _ in skeleton:
-            # float64 from here on (what the reference computes under NumPy < 2 promotion; also what
-            # Engine.pose_post / ph_pose_post computes on the device)
-            x, y = float(x), float(y)
-            patch = depth_img[max(0, int(y - patch_offset)):min(H, int(y + patch_offset)),
-                              max(0, int(x - patch_offset)):min(W, int(x + patch_offset))]
-            depth_avg = float(np.nanmean(patch)) if patch.size else float("nan")
-            x3d = (x - cx) / fx * depth_avg
-            y3d = (y - cy) / fy * depth_avg
-            joints3d.append([x3d * depth_scale, y3d * depth_scale, depth_avg * depth_scale])
-        return np.array(joints3d)
+        """One person: [J, 3] image joints -> [J, 3] camera-space joints (see :func:`lift_to_3d`)."""
+        return lift_to_3d(skeleton, depth_img, intr_mat, depth_scale, patch_offset)
 
     def convert_to_3d(self, depth_image: np.ndarray, intr_mat: Union[list, np.ndarray],
                       depth_scale: float = 1e-3) -> None:
-        if not self.pose_empty:
-            pose_keypoints_3d = []
-            for pose_keypoint in self.pose_keypoints:
-                pose_keypoints_3d.append(self.get_3d_skeleton(
-                    skeleton=pose_keypoint, depth_img=depth_image, intr_mat=intr_mat,
-                    depth_scale=depth_scale, patch_offset=self.patch_offset))
-            self._pose_keypoints_3d = np.asarray(pose_keypoints_3d)
-        return
+        if self.pose_empty:
+            return
+        self._pose_keypoints_3d = lift_to_3d(self.pose_keypoints, depth_image, intr_mat, depth_scale,
+                                             self.patch_offset)
 
+    # ---- writers
     @staticmethod
     def save_2d_skeleton(keypoints: Optional[np.ndarray], scores: Optional[np.ndarray], save_path: str) -> None:
-        # one CSV row per person: score, x0,y0,s0, ... (:186-199); empty file when nobody
-        os.makedirs(os.path.dirname(save_path), exist_ok=True)
-        if keypoints is None:
-            open(save_path, 'a').close()
-        else:
-            M, _, _ = keypoints.shape
-            data = np.concatenate([scores.reshape((M, 1)), keypoints.reshape((M, -1))], axis=1)
-            np.savetxt(save_path, data, delimiter=',')
+        write_people_csv(save_path, keypoints, scores)
 
     def save_pose_keypoints(self, save_path: str) -> None:
-        self.save_2d_skeleton(keypoints=self.pose_keypoints, scores=self.pose_scores, save_path=save_path)
-        return
+        write_people_csv(save_path, self.pose_keypoints, self.pose_scores)
 
     def save_3d_pose_keypoints(self, save_path: str) -> None:
-        self.save_2d_skeleton(keypoints=self.pose_keypoints_3d, scores=self.pose_scores, save_path=save_path)
-        return
+        write_people_csv(save_path, self.pose_keypoints_3d, self.pose_scores)
 
+    # ---- drawing (NumPy rasteriser, posehip/draw.py; off the hot path)
     @staticmethod
     def _draw_text_on_skeleton_image(image: Optional[np.ndarray] = None,
                                      scores: Optional[np.ndarray] = None) -> np.ndarray:
@@ -396,106 +411,108 @@ class PyOpenPoseNativeBase:
     @staticmethod
     def _draw_depth_on_skeleton_image(image: Optional[np.ndarray] = None,
                                       depth: Optional[np.ndarray] = None) -> np.ndarray:
-        if depth is not None and image is not None:
-            g = np.clip(np.abs(depth.astype(np.float32)) * 0.065, 0, 255).astype(np.uint8)
-            colormap = np.stack([g // 3, g // 2, g], axis=-1)   # stand-in for COLORMAP_INFERNO
-            image = np.clip(image.astype(np.float32) * 0.7 + colormap.astype(np.float32) * 0.7, 0, 255).astype(np.uint8)
-        return image
+        if depth is None or image is None:
+            return image
+        g = np.clip(np.abs(depth.astype(np.float32)) * 0.065, 0, 255).astype(np.uint8)
+        tint = np.stack([g // 3, g // 2, g], axis=-1).astype(np.float32)   # stand-in for COLORMAP_INFERNO
+        return np.clip((image.astype(np.float32) + tint) * 0.7, 0, 255).astype(np.uint8)
 
     @staticmethod
     def _draw_bounding_box_on_skeleton_image(image: np.ndarray, boxes: Optional[np.ndarray]) -> np.ndarray:
-        if boxes is not None:
-            for bb in boxes:
-                image = draw.rectangle(image, bb[0:2], bb[2:4], (0, 125, 0), 2)
+        for bb in ([] if boxes is None else boxes):
+            image = draw.rectangle(image, bb[0:2], bb[2:4], (0, 125, 0), 2)
         return image
 
     @staticmethod
     def _draw_tracking_bounding_box_image(image: np.ndarray, tracks: Optional[list] = None) -> np.ndarray:
-        if tracks is not None:
-            for track in tracks:
-                if track.is_activated:
-                    try:
-                        bb = track.to_tlbr()
-                    except AttributeError:
-                        bb = track.tlbr
-                    try:
-                        l, t, r, b = bb
-                        x1, y1 = int(np.floor(l)), int(np.floor(t))
-                        x2, y2 = int(np.ceil(r)), int(np.ceil(b))
-                        sub = image[y1:y2, x1:x2]
-                        rect = np.ones(sub.shape, dtype=np.float32) * np.array((60, 130, 0), dtype=np.float32)
-                        image[y1:y2, x1:x2] = np.clip(sub * 0.5 + rect * 0.5 + 1.0, 0, 255).astype(np.uint8)
-                    except TypeError:
-                        pass
+        """Half-transparent green patch over the box of every activated track (``to_tlbr()`` or ``.tlbr``)."""
+        tint = np.array((60, 130, 0), dtype=np.float32)
+        for track in (tracks or []):
+            if not track.is_activated:
+                continue
+            box = track.to_tlbr() if hasattr(track, "to_tlbr") else track.tlbr
+            try:
+                left, top, right, bottom = box
+            except TypeError:
+                continue
+            win = (slice(int(np.floor(top)), int(np.ceil(bottom))), slice(int(np.floor(left)), int(np.ceil(right))))
+            image[win] = np.clip((image[win] + tint) * 0.5 + 1.0, 0, 255).astype(np.uint8)
         return image
 
     def display(self, win_name: str, speed: int = 1000, scale: float = 1.0,
                 depth_image: Optional[np.ndarray] = None, bounding_box: bool = False,
                 tracks: Optional[list] = None, ori_image: Optional[np.ndarray] = None
                 ) -> Tuple[bool, Optional[np.ndarray]]:
-        image = self.opencv_image
-        image = self._draw_depth_on_skeleton_image(image, depth_image)
+        """No window is opened (no cv2 here): returns (True, the composed image) for the caller to show."""
+        def scaled(img):
+            return draw.resize_nearest(img, int(img.shape[1] * scale), int(img.shape[0] * scale))
+        canvas = self._draw_depth_on_skeleton_image(self.opencv_image, depth_image)
         if bounding_box:
-            image = self._draw_bounding_box_on_skeleton_image(image, self.pose_bounding_box_int)
+            canvas = self._draw_bounding_box_on_skeleton_image(canvas, self.pose_bounding_box_int)
         if tracks is not None:
-            image = self._draw_tracking_bounding_box_image(image, tracks)
-        image = draw.resize_nearest(image, int(image.shape[1] * scale), int(image.shape[0] * scale))
+            canvas = self._draw_tracking_bounding_box_image(canvas, tracks)
+        canvas = scaled(canvas)
         if ori_image is not None:
-            _image = draw.resize_nearest(ori_image, int(ori_image.shape[1] * scale), int(ori_image.shape[0] * scale))
-            image = np.concatenate([_image, image], axis=0)
-        return True, image
+            canvas = np.concatenate([scaled(ori_image), canvas], axis=0)
+        return True, canvas
 
     def save_skeleton_image(self, save_path: str, depth: Optional[np.ndarray] = None) -> None:
-        image = self.opencv_image
-        image = self._draw_depth_on_skeleton_image(image, depth)
-        os.makedirs(os.path.dirname(save_path), exist_ok=True)
         from PIL import Image
-        Image.fromarray(np.ascontiguousarray(image[:, :, ::-1])).save(save_path)
-        return
+        bgr = self._draw_depth_on_skeleton_image(self.opencv_image, depth)
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(save_path)
+
+
+_DEFAULT_PARAMS = {"model_folder": "/usr/local/src/openpose/models/", "model_pose": "BODY_25",
+                   "net_resolution": "-1x368"}
+_FORCED_PARAMS = {"disable_blending": True, "scale_number": 1, "body": 1}
 
 
 class PyOpenPoseNative(PyOpenPoseNativeBase):
-    """``native/python/skeleton.py:373-514``."""
+    """The estimator (interface of ``native/python/skeleton.py:373-514``) over :class:`Wrapper`."""
 
     def __init__(self, params: Optional[dict] = None, skel_thres: float = 0.0, max_true_body: int = 2,
                  patch_offset: int = 2) -> None:
         super().__init__(skel_thres, max_true_body, patch_offset)
         if params is None:
-            params = dict()
-            params["model_folder"] = "/usr/local/src/openpose/models/"
-            params["model_pose"] = "BODY_25"
-            params["net_resolution"] = "-1x368"
-        params["disable_blending"] = True
-        params["scale_number"] = 1
-        params["body"] = 1
-        self.params = params.copy()
-        self.params_cout = params.copy()
-        self.params_cin = params.copy()
+            params = dict(_DEFAULT_PARAMS)
+        params.update(_FORCED_PARAMS)          # (in the caller's dict too, as the reference does)
+        self.params, self.params_cout, self.params_cin = dict(params), dict(params), dict(params)
         self.opWrapper = Wrapper()
-        self.opWrapper.configure(self.params)
-        self.opWrapper.start()
+        self.configure(self.params, restart=False)
         self.filtered_skel = "0"
         self.reset()
 
     def reset(self) -> None:
         super().reset()
         self.filtered_skel = "0"
-        return
 
-    def configure(self, params: dict = None) -> None:
-        if params is not None:
+    def configure(self, params: dict = None, restart: bool = True) -> None:
+        """Stop, re-configure and start the engine; ``None`` leaves it as it is."""
+        if params is None:
+            return
+        if restart:
             self.opWrapper.stop()
-            self.opWrapper.configure(params)
-            self.opWrapper.start()
-        return
+        self.opWrapper.configure(params)
+        self.opWrapper.start()
 
-    def predict(self, image: np.ndarray) -> None:
+    def _process(self, image: np.ndarray, custom: Optional[List[np.ndarray]] = None, raw: bool = False) -> None:
+        """One frame through the wrapper into ``self.datum``."""
         self.reset()
         self.datum.cvInputData = image
-        self.opWrapper.emplaceAndPop([self.datum])
-        if self.datum.poseScores is None:
-            self._pose_empty = True
-        return
+        if custom is not None:
+            self.datum.customInputNetData = custom
+        self.opWrapper.want_raw = raw
+        try:
+            self.opWrapper.emplaceAndPop([self.datum])
+        finally:
+            self.opWrapper.want_raw = False
+            if custom is not None:
+                self.datum.customInputNetData = []
+        self._pose_empty = self.datum.poseScores is None
+
+    def predict(self, image: np.ndarray) -> None:
+        self._process(image)
 
     def predict_batch(self, images) -> List[Tuple[Optional[np.ndarray], Optional[np.ndarray]]]:
         """Addition: one call for a batch of equally sized frames.  Returns
@@ -517,57 +534,35 @@ class PyOpenPoseNative(PyOpenPoseNativeBase):
         the properties, ``filter_prediction`` and the writers act on it as after ``predict``."""
         self.reset()
         self.datum = datum
-        if datum.poseScores is None:
-            self._pose_empty = True
+        self._pose_empty = datum.poseScores is None
 
     def predict_hm(self, image: np.ndarray, hm_save_path: str) -> None:
-        # raw net output -> .float file: f32 [ndim, d0..d3, data...] (:452-467)
-        self.reset()
-        self.datum.cvInputData = image
-        self.opWrapper.want_raw = True
-        try:
-            self.opWrapper.emplaceAndPop([self.datum])
-        finally:
-            self.opWrapper.want_raw = False
+        """Predict and dump the raw net output as a ``.float`` file: float32 [ndim, d0, d1, d2, d3, data...]
+        (the header-prefixed write of the reference, :460-464; reader: :func:`read_heatmap_file`)."""
+        self._process(image, raw=True)
         os.makedirs(os.path.dirname(hm_save_path), exist_ok=True)
         raw = self.datum.poseRawHeatMaps[0]
-        np.insert(raw.reshape(-1), [0, 0, 0, 0, 0], [raw.ndim] + list(raw.shape)).tofile(hm_save_path)
-        if self.datum.poseScores is None:
-            self._pose_empty = True
-        return
+        header = np.asarray((raw.ndim,) + raw.shape, dtype=raw.dtype)
+        np.concatenate([header, raw.reshape(-1)]).tofile(hm_save_path)
 
     def predict_from_hm(self, image: np.ndarray, heatmap: Optional[List[np.ndarray]] = None) -> None:
-        self.reset()
-        self.datum.cvInputData = image
-        self.datum.customInputNetData = heatmap
-        self.opWrapper.emplaceAndPop([self.datum])
-        self.datum.customInputNetData = []
-        if self.datum.poseScores is None:
-            self._pose_empty = True
-        return
+        """Decode-only: `heatmap` = [net output f32 [1, C, hs, ws]] is injected instead of running the network."""
+        self._process(image, custom=heatmap if heatmap is not None else [])
 
     def filter_prediction(self) -> None:
-        # keeps the reference's behaviour: only `filtered_skel` changes (:483-514)
+        """Keep the ``max_true_body`` best people with a score of at least ``skel_thres``.  As in the reference
+        (:483-514) the kept arrays go to ``_pose_keypoints`` / ``_pose_scores``, which no property reads: the public
+        results stay unfiltered and only ``filtered_skel`` ("kept/total") reports the outcome."""
         if self.pose_empty:
-            pass
+            return
+        scores = self.pose_scores
+        keep = strongest_people(scores, self.max_true_body, self.skel_thres)
+        if keep.size:
+            self._pose_keypoints = self.pose_keypoints[keep]
+            self._pose_scores = scores[keep]
         else:
-            scores = self.pose_scores
-            scores_filtered = []
-            keypoints_filtered = []
-            max_score_idxs = np.argsort(scores)[-self.max_true_body:]
-            for max_score_idx in max_score_idxs:
-                if scores[max_score_idx] < self.skel_thres:
-                    continue
-                else:
-                    keypoints_filtered.append(self.pose_keypoints[max_score_idx])
-                    scores_filtered.append(scores[max_score_idx])
-            if len(scores_filtered) == 0:
-                self.reset()
-            else:
-                self._pose_keypoints = np.stack(keypoints_filtered, axis=0)
-                self._pose_scores = np.stack(scores_filtered, axis=0)
-            self.filtered_skel = f"{len(keypoints_filtered)}/{len(scores)}"
-        return
+            self.reset()
+        self.filtered_skel = f"{keep.size}/{len(scores)}"
 
     def pose_track_features(self, image_size: Optional[Tuple[int, int]] = None,
                             size: Tuple[int, int] = (25, 50)) -> Optional[np.ndarray]:
@@ -592,31 +587,32 @@ def read_heatmap_file(path: str) -> List[np.ndarray]:
     return [hm[5:].reshape(int(hm[1]), int(hm[2]), int(hm[3]), int(hm[4]))]
 
 
+# argparse flag (openpose/native/python/args.py) -> OpenPose parameter
+_FLAG_TO_PARAM = {"op_model_folder": "model_folder", "op_model_pose": "model_pose",
+                  "op_net_resolution": "net_resolution", "op_heatmaps_add_parts": "heatmaps_add_parts",
+                  "op_heatmaps_add_bkg": "heatmaps_add_bkg", "op_heatmaps_add_PAFs": "heatmaps_add_PAFs",
+                  "op_heatmaps_scale": "heatmaps_scale"}
+_POSEHIP_FLAGS = ("posehip_random_weights", "posehip_device", "posehip_batch")
+
+
 class OpenPosePoseExtractor:
-    """``native/python/skeleton.py:517-608``."""
+    """The argparse-driven facade (interface of ``native/python/skeleton.py:517-608``)."""
 
     def __init__(self, args: argparse.Namespace) -> None:
-        params = dict(
-            model_folder=args.op_model_folder,
-            model_pose=args.op_model_pose,
-            net_resolution=args.op_net_resolution,
-            heatmaps_add_parts=args.op_heatmaps_add_parts,
-            heatmaps_add_bkg=args.op_heatmaps_add_bkg,
-            heatmaps_add_PAFs=args.op_heatmaps_add_PAFs,
-            heatmaps_scale=args.op_heatmaps_scale,
-            render_pose=-1 if args.op_display > 0 else 0,
-        )
-        for k in ("posehip_random_weights", "posehip_device", "posehip_batch"):
-            if getattr(args, k, None) is not None:
-                params[k] = getattr(args, k)
+        params = {param: getattr(args, flag) for flag, param in _FLAG_TO_PARAM.items()}
+        params["render_pose"] = -1 if args.op_display > 0 else 0
+        params.update({k: getattr(args, k) for k in _POSEHIP_FLAGS if getattr(args, k, None) is not None})
         self.pyop = PyOpenPoseNative(params, args.op_skel_thres, args.op_max_true_body, args.op_patch_offset)
+
+    def _after(self, kpt_save_path: Optional[str]) -> None:
+        self.pyop.filter_prediction()
+        if kpt_save_path is not None:
+            self.pyop.save_pose_keypoints(kpt_save_path)
 
     def predict(self, image: np.ndarray, depth: np.ndarray, kpt_save_path: Optional[str] = None,
                 skel_image_save_path: Optional[str] = None) -> None:
         self.pyop.predict(image)
-        self.pyop.filter_prediction()
-        if kpt_save_path is not None:
-            self.pyop.save_pose_keypoints(kpt_save_path)
+        self._after(kpt_save_path)
         if skel_image_save_path is not None:
             self.pyop.save_skeleton_image(skel_image_save_path, depth)
 
@@ -626,9 +622,7 @@ class OpenPosePoseExtractor:
     def predict_from_hm(self, image: np.ndarray, heatmap: Optional[List[np.ndarray]] = None,
                         kpt_save_path: Optional[str] = None) -> None:
         self.pyop.predict_from_hm(image, heatmap)
-        self.pyop.filter_prediction()
-        if kpt_save_path is not None:
-            self.pyop.save_pose_keypoints(kpt_save_path)
+        self._after(kpt_save_path)
 
     def predict_3d(self, image: np.ndarray, depth: np.ndarray, intr_mat: np.ndarray, depth_scale: float = 1e-3,
                    kpt_save_path: Optional[str] = None, kpt_3d_save_path: Optional[str] = None,
@@ -641,15 +635,14 @@ class OpenPosePoseExtractor:
     def display(self, win_name: str = "1", speed: int = 1000, scale: int = 1.0,
                 image: Optional[np.ndarray] = None, bounding_box: bool = False,
                 tracks: list = None) -> Tuple[bool, Optional[np.ndarray]]:
-        if scale > 0:
-            if self.pyop.datum.poseScores is None:
-                img = self.pyop.opencv_image
-                if image is not None:
-                    _image = draw.resize_nearest(image, int(image.shape[1] * scale), int(image.shape[0] * scale))
-                    img = np.concatenate([_image, img], axis=0)
-                return True, img
-            else:
-                return self.pyop.display(win_name, scale=scale, speed=speed, bounding_box=bounding_box,
-                                         tracks=tracks, ori_image=image)
-        else:
+        """(True, composed image) -- or (True, None) for a scale of 0 or less; nothing is shown on screen."""
+        if not scale > 0:
             return True, None
+        if self.pyop.datum.poseScores is not None:
+            return self.pyop.display(win_name, scale=scale, speed=speed, bounding_box=bounding_box, tracks=tracks,
+                                     ori_image=image)
+        canvas = self.pyop.opencv_image
+        if image is not None:
+            top = draw.resize_nearest(image, int(image.shape[1] * scale), int(image.shape[0] * scale))
+            canvas = np.concatenate([top, canvas], axis=0)
+        return True, canvas

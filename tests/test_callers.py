@@ -323,3 +323,44 @@ def test_offline_walk_runtime_resets_after_warmup(tmp_path):
     n0 = len(pe.calls)
     inference.extract_2dskeletons_online(args, pe, max_passes=2)
     assert len(pe.calls) - n0 == 36
+
+
+def test_cv2_flavour_writers_file_layout(tmp_path):
+    """save_keypoints / save_personwise_keypoints (openpose/opencv/inference.py:17-30): one appended line of
+    comma-joined Python-float reprs per call."""
+    from posehip import bench_opencv
+    kl = np.array([[12.0, 7.0, 0.8125], [300.0, 41.0, 0.25]])
+    p = str(tmp_path / "kptl.txt")
+    bench_opencv.save_keypoints(kl, p)
+    bench_opencv.save_keypoints(np.zeros((0, 3)), p)                       # nobody: an empty line
+    bench_opencv.save_keypoints(kl[:1], p)
+    assert open(p).read() == "12.0,7.0,0.8125,300.0,41.0,0.25\n\n12.0,7.0,0.8125\n"
+    # exactly what the reference's expression produces
+    want = ",".join([str(i) for keypoint in kl.tolist() for i in keypoint])
+    assert open(p).read().split("\n")[0] == want
+    people = [np.array([0., 1., -1., 2.5]), np.array([3., -1., 4., 1.75])]
+    q = str(tmp_path / "people.txt")
+    bench_opencv.save_personwise_keypoints(people, q)
+    bench_opencv.save_personwise_keypoints([], q)
+    assert open(q).read() == "0.0,1.0,-1.0,2.5,3.0,-1.0,4.0,1.75\n\n"
+    assert open(q).read().split("\n")[0] == ",".join([str(i) for k in people for i in k.tolist()])
+    # the reference's import lines resolve through compat/
+    import importlib
+    import os
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "compat")
+    sys.path.insert(0, compat)
+    try:
+        for name in list(sys.modules):
+            if name == "openpose" or name.startswith("openpose."):
+                del sys.modules[name]
+        m = importlib.import_module("openpose.opencv.inference")
+        assert m.save_keypoints is bench_opencv.save_keypoints
+        t = importlib.import_module("openpose.native.python.test")
+        assert callable(t.test_op_runtime)
+    finally:
+        sys.path.remove(compat)
+    # frame loader: BGR u8 of the asked size, from the reference's JPEG when it is there, seeded noise otherwise
+    f = bench_opencv.load_frame("/nonexistent.jpg", 64)
+    assert f.shape == (64, 64, 3) and f.dtype == np.uint8
+    np.testing.assert_array_equal(f, bench_opencv.load_frame("", 64))

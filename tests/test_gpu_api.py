@@ -390,3 +390,27 @@ def test_tracker_features_device_equals_host_path():
     for w, f in zip(want, feats):
         np.testing.assert_array_equal(w.feature, f)
     pyop.opWrapper.close()
+
+
+def test_reference_timing_harnesses_run_through_the_estimator_classes(tmp_path, capsys):
+    """The reference's two timing scripts (openpose/opencv/inference.py:33-89, native/python/test.py:9-48) as
+    posehip.bench_opencv.run / posehip.bench_native.test_op_runtime: they drive the estimator classes, append one
+    keypoint line per iteration and print the reference's summary lines."""
+    from posehip import bench_native, bench_opencv
+    out = str(tmp_path / "cv")
+    mean, kl, people = bench_opencv.run("/nonexistent.jpg", out, iters=3, random_weights=0, image_width=128,
+                                        image_height=96)
+    files = sorted(os.listdir(out))
+    assert 1 <= len(files) <= 3 and all(f.startswith("kptl") and f.endswith(".txt") for f in files)
+    lines = [ln for f in files for ln in open(os.path.join(out, f)).read().split("\n")[:-1]]
+    assert len(lines) == 3
+    assert lines[-1] == ",".join(str(v) for v in np.asarray(kl).reshape(-1).tolist())
+    assert mean > 0 and kl.shape[1] == 3
+    assert "Average inference time over 3 trials" in capsys.readouterr().out
+    per_frame, fps, pyop = bench_native.test_op_runtime("/nonexistent.jpg", str(tmp_path / "nat"), iters=6,
+                                                        net_resolution="-1x64", random_weights=0, save=True)
+    text = capsys.readouterr().out
+    assert "Average inference time over 3 trials" in text and "fps" in text
+    assert per_frame > 0 and fps > 0 and "/" in pyop.filtered_skel or pyop.pose_empty
+    assert os.path.exists(tmp_path / "nat" / "predictions.txt")
+    pyop.opWrapper.close()
