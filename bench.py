@@ -37,7 +37,9 @@ def cpu_baseline(net, weights, model, n_frames, seed):
     import torch
     from oracle import decode_v2, net_ref
     from posehip import synth
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    # threads actually used: the box's CPU share (OMP_NUM_THREADS, 16 per GPU on the pool's boxes -- os.cpu_count()
+    # there shows the whole machine, which one GPU job may not use) or, where that is not set, every host core
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     torch.set_num_threads(cores)
     frames = synth.synth_frames(seed, n_frames, NET_H, NET_W)
     t0 = time.time()
@@ -46,9 +48,37 @@ def cpu_baseline(net, weights, model, n_frames, seed):
         out = net_ref.forward(net, weights, x)
         decode_v2.decode(out[0], model, NET_H, NET_W, 1.0)
     dt = time.time() - t0
-    return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "host_cpu_count": os.cpu_count(),
+            "kind": "port",
             "sample": f"{n_frames} synthetic 368x656 frames, batch 1, torch-CPU fp32 forward + NumPy V2 decode "
                       f"(oracle/net_ref.py + oracle/decode_v2.py); cv2.dnn/pyopenpose unavailable"}
+
+
+def tail_block(B, src_h, src_w, pre_ms, decode_ms, paf_pairs):
+    """HBM-side view of the memory-bound tail (north star: achieved GB/s of resize / NMS / PAF against the
+    MI355X peak), per launch of B frames.  Bytes are ALGORITHMIC, durations are HIP events of this run:
+      preprocess  read H0*W0*3 u8 + write Hn*Wn*3 bf16 per frame
+      upsample+NMS  what upstream's resizeAndMerge -> nms moves: read 78 net-output planes, write 78 upsampled maps,
+                  read the 25 part maps back (100.6 MB/frame); the fused kernels read 25 planes once (`fused_bytes`)
+      PAF scoring  pairs x <=25 samples x 2 channels x 4 B gathered (pairs counted on this run's peaks)
+    A fraction above 1 only says the materialised traffic of the unfused algorithm never happens here."""
+    hbm = 8000.0
+    hs, ws = NET_H // 8, NET_W // 8
+    rows = {
+        "preprocess_kernel": (B * (src_h * src_w * 3 + NET_H * NET_W * 3 * 2), None, pre_ms),
+        "nms_detect_cols_kernel+nms_refine_kernel": (B * (78 * hs * ws * 4 + 78 * NET_H * NET_W * 4 + 25 * NET_H * NET_W * 4),
+                                                      B * 25 * hs * ws * 4, float(decode_ms[0])),
+        "paf_score_kernel": (paf_pairs * 25 * 2 * 4, None, float(decode_ms[1])),
+    }
+    out = {}
+    for k, (alg, fused, ms) in rows.items():
+        gbs = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[k] = {"algorithmic_bytes": int(alg), "us": round(ms * 1e3, 1), "GB_per_s": round(gbs, 1),
+                  "frac_of_8TBps": round(gbs / hbm, 4)}
+        if fused is not None:
+            out[k]["fused_bytes"] = int(fused)
+    out["assemble_merge_kernel"] = {"us": round(float(decode_ms[2]) * 1e3, 1), "bound": "latency (one block per frame)"}
+    return out
 
 
 def main():
@@ -143,13 +173,11 @@ def main():
     g = {}
     if gather:
         gdev = dev if backend == "nccl" else torch.device("cpu")
-        if backend == "nccl":   # one gathered record set per engine: gathers of different engines may overlap
-            for d in bufs:
-                d["gpack"] = torch.empty((world, d["pack"].numel()), dtype=torch.float32, device=gdev)
-        else:
-            g["N"] = torch.empty((world * B,), dtype=torch.int32, device=gdev)
-            g["KP"] = torch.empty((world * B, MAX_PEOPLE, J, 3), dtype=torch.float32, device=gdev)
-            g["SC"] = torch.empty((world * B, MAX_PEOPLE), dtype=torch.float32, device=gdev)
+        # rank 0 only: one gathered record set per engine (gathers of different engines may overlap)
+        for d in bufs:
+            d["gbins"] = [torch.empty((d["pack"].numel(),), dtype=torch.float32, device=gdev)
+                          for _ in range(world)] if rank == 0 else None
+            d["hpack"] = torch.empty((d["pack"].numel(),), dtype=torch.float32).pin_memory()
     cur = torch.cuda.current_stream()
     trace = (lambda *a: print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)) if os.environ.get("BENCH_TRACE") \
         else (lambda *a: None)
@@ -171,38 +199,62 @@ def main():
             e.decode_v2_dev(BODY_25, B, NET_H, NET_W, kp_scale, MAX_PEOPLE)
             # results to pinned host memory (rank-local) ...
             e.decode_v2_results(d["n"], d["kp"], d["sc"])
-        if gather and backend == "nccl":  # ... and one RCCL all_gather of the padded tensors (rank 0 keeps it)
+        if gather and backend == "nccl":  # ... and ONE RCCL gather of the packed, padded record to rank 0
             e.decode_v2_results(d["gn"], d["gkp"], d["gsc"])
             # Issued with the ENGINE's stream current: the collective waits for this batch's decode only, and
             # only this engine's next batch waits for the collective.  (Issuing every gather from one common
             # stream and making the engines wait for that stream serializes the batches in flight: -12 %.)
             with torch.cuda.stream(ts):
-                dist.all_gather_into_tensor(d["gpack"], d["pack"])
-        elif gather:  # rehearsal backend (gloo): same control flow, gather of the host copies
+                dist.gather(d["pack"], d["gbins"], dst=0)
+        elif gather:  # rehearsal backend (gloo): same control flow, gather of a host copy of the record
+            e.decode_v2_results(d["gn"], d["gkp"], d["gsc"])
+            with torch.cuda.stream(ts):
+                d["hpack"].copy_(d["pack"], non_blocking=True)
             ts.synchronize()
-            dist.all_gather_into_tensor(g["N"], d["n"])
-            dist.all_gather_into_tensor(g["KP"], d["kp"])
-            dist.all_gather_into_tensor(g["SC"], d["sc"])
+            dist.gather(d["hpack"], d["gbins"], dst=0)
         trace("step", i, "enqueued")
 
-    for i in range(args.warmup):
-        step(i)
-    trace("warmup done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    def timed(n_warm, n_steps):
+        """W untimed + exactly K timed steps, bracketed by barrier + synchronize; max over ranks."""
+        for i in range(n_warm):
+            step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    dt = timed(args.warmup, args.steps)
     trace("timed region done", dt)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # what rank 0 gathered for its own shard must be what it decoded (the last step of every engine in flight)
+    gather_checked = None
+    if gather and rank == 0 and not os.environ.get("BENCH_DIAG_NO_DECODE"):
+        n_kp, n_sc = B * MAX_PEOPLE * J * 3, B * MAX_PEOPLE
+        for d in bufs[:min(S, args.steps + args.warmup)]:
+            mine = d["gbins"][0].cpu()
+            cnt = mine[n_kp + n_sc:].view(torch.int32)
+            assert torch.equal(cnt, d["n"]), "gathered people counts differ from the rank-local decode"
+            for b in range(B):
+                m = min(int(cnt[b]), MAX_PEOPLE)
+                assert torch.equal(mine[:n_kp].view(B, MAX_PEOPLE, J, 3)[b, :m], d["kp"][b, :m])
+        gather_checked = "rank 0's own shard: gathered counts and keypoints equal the local decode"
+    # the PCIe-inclusive rate beside the headline (SURVEY 8d defines the metric with the H2D copy): same steps with
+    # the frames copied from pinned host memory every step.  Reported, never `value`.
+    dt_h2d = None
+    if not args.h2d and not os.environ.get("BENCH_NO_H2D_LEG"):
+        args.h2d = True
+        dt_h2d = timed(min(args.warmup, 2), args.steps)
+        args.h2d = False
 
     # Kernel durations for the roofline: the same steps once more on ONE engine, serialized, with a HIP event
     # around every op on its stream (under --streams > 1 the timed region overlaps kernels of different
@@ -211,8 +263,14 @@ def main():
     op_ms_total = np.zeros(len(plan.ops))
     decode_ms = np.zeros(3)
     n_prof = max(1, min(args.steps, 10)) if rank == 0 else 0
+    pre_ms = 0.0
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(n_prof):
+        with torch.cuda.stream(tstreams[0]):      # events on the stream the kernel is launched on
+            ev0.record()
         eng.preprocess(bufs[0]["frames"], _ffi.PH_PRE_NATIVE)
+        with torch.cuda.stream(tstreams[0]):
+            ev1.record()
         eng.forward_timed(B, wait=False)
         eng.decode_v2_dev(BODY_25, B, NET_H, NET_W, kp_scale, MAX_PEOPLE)
         tstreams[0].synchronize()
@@ -220,7 +278,13 @@ def main():
         conv_ms_total += float(ms[conv_mask].sum())
         op_ms_total += ms
         decode_ms += np.array(eng.decode_v2_times())
-    frames = bufs[0]["frames"]
+        pre_ms += ev0.elapsed_time(ev1)
+    # candidate pairs the PAF kernel scored (its algorithmic bytes depend on the peak counts)
+    paf_pairs = 0
+    if rank == 0:
+        _, ex = eng.decode_v2(BODY_25, B, NET_H, NET_W, kp_scale, MAX_PEOPLE, want_peaks=True)
+        npk = ex["peaks"][:, :, 0, 0].astype(np.int64)                      # [B, parts]
+        paf_pairs = int(sum((npk[:, a] * npk[:, b]).sum() for a, b in BODY_25.pairs))
 
     if rank == 0 and args.per_op:
         ms = eng.forward_timed(B)
@@ -258,7 +322,7 @@ def main():
         d_ms, d_fl, d_n = by_k[dom]
         d_ach = d_fl / (d_ms / 1e3) / 1e12 if d_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if os.path.exists(tpath):  # PMC passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE) of this same command
             with open(tpath) as fh:
                 traffic = json.load(fh).get("bytes_per_launch", {}).get(dom)
@@ -274,7 +338,8 @@ def main():
                        "batch_per_gpu": B, "net_resolution": f"{NET_W}x{NET_H}", "source_frames": f"{src_w}x{src_h}", "weights": "random He-normal",
                        "frames": "pinned host, H2D every step" if args.h2d else "resident in HBM",
                        "batches_in_flight_per_gpu": S,
-                       "parallelism": f"frame-parallel x{world}, RCCL keypoint all_gather"},
+                       "parallelism": f"frame-parallel x{world}, one RCCL gather of the packed keypoint record to "
+                                      "rank 0 per step"},
             "roofline": {"bound": "mfma", "achieved": round(d_ach, 2), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(d_ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": dom,
@@ -289,11 +354,22 @@ def main():
                                       "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
                                       "per_kernel_ms_per_step": {k: round(v[0] / n_prof, 3)
                                                                  for k, v in sorted(by_k.items())}},
+                         "traffic_source": "profiles/r02_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE of rocprofv3 PMC "
+                                           "passes of this command on the profiling box (not measured in this run)",
                          "decode_ms_per_step": [round(float(x) / n_prof, 3) for x in decode_ms],
+                         "tail": tail_block(B, src_h, src_w, pre_ms / n_prof, decode_ms / n_prof, paf_pairs),
                          # whole-pipeline view: frames/s x algorithmic FLOPs per frame against the MFMA peak of
                          # the GPUs used (100 % = 8 700 frames/s per GPU)
                          "end_to_end_frac_of_mfma_peak": round(fps * flops_frame / (world * MFMA_PEAK_TFLOPS * 1e12), 4)},
         }
+        if dt_h2d is not None:
+            line["h2d_inclusive"] = {"value": round(world * B * args.steps / dt_h2d, 2), "unit": "frames/s",
+                                     "ms_per_step": round(dt_h2d / args.steps * 1e3, 3),
+                                     "note": f"same {args.steps} steps with the u8 frames copied from pinned host "
+                                             f"memory every step ({B * src_h * src_w * 3 / 1e6:.1f} MB/step over "
+                                             "PCIe); reported beside `value`, never as it"}
+        if gather_checked:
+            line["config"]["gather_check"] = gather_checked
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(net, weights, BODY_25, args.cpu_frames, 1000)
         sys.stdout.flush()

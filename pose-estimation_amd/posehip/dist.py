@@ -7,7 +7,7 @@ internal ``num_gpu`` frame-parallel workers (push N frames, pop N in order:
 ``openpose/native/tutorial_api_python/05_keypoints_from_images_multi_gpu.py:71-96``).
 This module is the MI355X counterpart: ``torch.distributed`` with the ``nccl``
 backend (= RCCL over xGMI) on GPUs, ``gloo`` on CPU for the tests.  Messages are
-fixed-shape so one ``all_gather_into_tensor`` per tensor suffices: per frame
+fixed-shape so ONE ``gather`` (dst = rank 0) of one packed record block suffices: per frame
 ``kp f32 [max_people, J, 3]`` + ``score f32 [max_people]`` + ``count i32`` =
 ~39 KB at max_people=128, J=25 -- latency-bound, four orders of magnitude under
 one 153 GB/s xGMI link, so a direct gather (not a ring of large buckets) is right.
@@ -42,31 +42,40 @@ def pad_results(results, max_people: int, n_parts: int) -> Tuple[np.ndarray, np.
     return cnt, kp, sc
 
 
+def pack_records(ids, cnt, kp, sc):
+    """One fixed-size float32 record block per rank: [n, 2 + M*J*3 + M] = frame id, count, keypoints, scores per
+    frame (ids / counts stored as float32: exact below 2^24).  One block = ONE collective per gather."""
+    import torch
+    n = cnt.shape[0]
+    return torch.cat([ids.reshape(n, 1).to(torch.float32), cnt.reshape(n, 1).to(torch.float32),
+                      kp.reshape(n, -1), sc.reshape(n, -1)], dim=1).contiguous()
+
+
 def gather_to_rank0(cnt, kp, sc, frame_ids, n_frames: int, group=None):
     """All ranks call this with their padded local results (torch tensors on the
     rank's device, equal leading size on every rank; pad short shards with
-    frame id -1).  Rank 0 returns results re-assembled in frame order:
-    list of (kp [M,J,3], score [M]) numpy arrays; other ranks return None."""
+    frame id -1).  ONE ``torch.distributed.gather`` to rank 0 (on the ``nccl`` backend: RCCL point-to-point over
+    xGMI, only rank 0 receives -- the north star's "gather keypoint tensors to rank 0").  Rank 0 returns results
+    re-assembled in frame order: list of (kp [M,J,3], score [M]) numpy arrays; other ranks return None."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ids = torch.as_tensor(np.asarray(frame_ids, np.int32)).to(cnt.device)
-    outs = []
-    for t in (ids, cnt, kp, sc):
-        t = t.contiguous()
-        g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(g, t, group=group)
-        outs.append(g)
+    rec = pack_records(ids, cnt, kp, sc)
+    bins = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
+    dist.gather(rec, bins, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     if rank != 0:
         return None
-    ids_g, cnt_g, kp_g, sc_g = (o.cpu().numpy() for o in outs)
+    M, J = kp.shape[1], kp.shape[2]
+    allrec = torch.cat(bins, dim=0).cpu().numpy()
     res: List[Optional[Tuple[np.ndarray, np.ndarray]]] = [None] * n_frames
-    for j, fid in enumerate(ids_g):
+    for row in allrec:
+        fid = int(row[0])
         if fid < 0:
             continue
-        m = int(cnt_g[j])
-        res[int(fid)] = (kp_g[j, :m].copy(), sc_g[j, :m].copy())
+        m = int(row[1])
+        res[fid] = (row[2:2 + M * J * 3].reshape(M, J, 3)[:m].copy(), row[2 + M * J * 3:][:m].copy())
     return res
 
 
