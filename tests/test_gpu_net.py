@@ -204,3 +204,62 @@ def test_body25_batch32_production_tiles_meet_the_oracle(engine):
         engine.preprocess(frames[k:k + 1], _ffi.PH_PRE_NATIVE)
         engine.forward(1)
         np.testing.assert_array_equal(engine.net_out(1)[0], got[k])
+
+
+def test_coco_full_size_forward_and_v1_decode(engine):
+    """BASELINE configs[2] geometry: the COCO-18 graph (7x7 refinement stages on the im2col kernel) at 368x656,
+    B = 2, against the torch fp32 oracle; then the V1 decode (postprocess_multi semantics, 1920x1080 target) of the
+    GPU's OWN network output against the oracle's decode of that output, bit for bit."""
+    from oracle import decode_v1, net_ref
+    from posehip import synth, tables
+    H, W = 368, 656
+    net = caffe_io.parse_prototxt(caffe_io.coco_prototxt(H, W))
+    weights = graph.random_weights(net, seed=13)
+    plan = graph.build_plan(net, weights)
+    engine.build(plan, 2)
+    assert any(k.startswith("conv_igemm_kernel") for k in engine.op_kernels())      # the 7x7 layers
+    frames = synth.synth_frames(55, 2, H, W)
+    engine.preprocess(frames, _ffi.PH_PRE_CV2)
+    engine.forward(2)
+    got = engine.net_out(2)
+    assert got.shape == (2, 57, 46, 82) and np.isfinite(got).all()
+    x = frames[1:2].astype(np.float32).transpose(0, 3, 1, 2) * np.float32(1 / 255.0)
+    ref = net_ref.forward(net, weights, x)
+    err = np.abs(got[1] - ref[0]).max()
+    assert err < 1e-2, err
+    assert err / (np.abs(ref).max() + 1e-9) < 3e-2
+    bp, pp = tables.get_body_parts_and_pose_pairs("COCO")
+    # random weights give noise maps: a threshold at their 99.7th percentile leaves a few dozen blobs per part
+    # (the default 0.1 would exceed the 8192 mask runs per part the decode is sized for)
+    thr = float(np.quantile(got[1, :18], 0.997))
+    res = engine.decode_v1(bp, pp, tables.MAPIDX, 2, 1920, 1080, thr)
+    kl_o, people_o = decode_v1.postprocess_multi(got[1:2], bp, pp, tables.MAPIDX, 1920, 1080, thr)
+    assert len(kl_o) > 18
+    np.testing.assert_array_equal(res[1][0], kl_o)
+    assert len(res[1][1]) == len(people_o)
+    for a, b in zip(res[1][1], people_o):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_body25_single_frame_368x368(engine):
+    """BASELINE configs[0] geometry: one 368x368 frame through BODY_25 (single-frame tile selection) against the
+    oracle, and its V2 decode against the oracle's decode of the same output."""
+    from oracle import decode_v2, net_ref
+    from posehip import synth
+    from posehip.tables import BODY_25
+    H = W = 368
+    net = caffe_io.parse_prototxt(caffe_io.body25_prototxt(H, W))
+    weights = graph.random_weights(net, seed=17)
+    engine.build(graph.build_plan(net, weights), 1)
+    frame = synth.synth_frames(99, 1, H, W)
+    engine.preprocess(frame, _ffi.PH_PRE_NATIVE)
+    engine.forward(1)
+    got = engine.net_out(1)
+    x = frame.astype(np.float32).transpose(0, 3, 1, 2) * np.float32(1 / 256.0) - np.float32(0.5)
+    ref = net_ref.forward(net, weights, x)
+    assert got.shape == (1, 78, 46, 46)
+    assert np.abs(got - ref).max() < 1e-2
+    res, _ = engine.decode_v2(BODY_25, 1, H, W, 1.0, 128)
+    kp_o, sc_o = decode_v2.decode(got[0], BODY_25, H, W, 1.0)
+    np.testing.assert_array_equal(res[0][0], kp_o)
+    np.testing.assert_array_equal(res[0][1], sc_o)
