@@ -414,3 +414,30 @@ def test_reference_timing_harnesses_run_through_the_estimator_classes(tmp_path, 
     assert per_frame > 0 and fps > 0 and "/" in pyop.filtered_skel or pyop.pose_empty
     assert os.path.exists(tmp_path / "nat" / "predictions.txt")
     pyop.opWrapper.close()
+
+
+def test_native_estimator_on_a_1080p_frame_scales_keypoints_back(tmp_path):
+    """BASELINE configs[4] geometry through the estimator class: a 1920x1080 frame at "-1x368" -> 656x368 net input
+    (cv::warpAffine down-scale, s = 0.3401), decode at net resolution, keypoints multiplied by upstream's
+    mScaleNetToOutput (2.9433, not 1/s) with the NMS offset 0.5 / scale -- equal to the oracle's decode of the same
+    net output with the oracle's own scale, bit for bit."""
+    from oracle import decode_v2
+    params = dict(model_folder="/nonexistent/", model_pose="BODY_25", net_resolution="-1x368",
+                  posehip_random_weights=3, number_people_max=512)
+    pyop = api_native.PyOpenPoseNative(params, 0.0, 2, 2)
+    img = synth.synth_frames(8, 1, 1080, 1920)[0]
+    hm_path = str(tmp_path / "hm.float")
+    pyop.predict_hm(img, hm_path)
+    assert (pyop.datum.netInputSizes[0].x, pyop.datum.netInputSizes[0].y) == (656, 368)
+    raw = api_native.read_heatmap_file(hm_path)[0]
+    assert raw.shape == (1, 78, 46, 82)
+    scale = decode_v2.scale_net_to_output(1920, 1080, 656, 368)
+    assert abs(float(scale) - 1919 / 652) < 1e-6 and float(scale) == api_native.scale_net_to_output(1920, 1080, 656, 368)
+    kp_o, sc_o = decode_v2.decode(raw[0], BODY_25, 368, 656, float(scale))
+    if len(sc_o) == 0:
+        assert pyop.pose_empty
+    else:
+        np.testing.assert_array_equal(pyop.pose_keypoints, kp_o)
+        np.testing.assert_array_equal(pyop.pose_scores, sc_o)
+        assert pyop.pose_keypoints[..., 0].max() > 656 and pyop.pose_keypoints[..., 1].max() > 368   # image pixels
+    pyop.opWrapper.close()
