@@ -22,11 +22,13 @@ path and cv2 cannot be imported.  ``blob_peaks`` is getKeypoints
 literally: Suzuki-Abe border following as OpenCV 4.5 contours.cpp codes it (outer
 AND hole borders, RETR_TREE list order = latest sibling first, node before its
 children), the CHAIN_APPROX_SIMPLE vertices, FillConvexPoly's outline + two-walker
-scan fill, first raster maximum of mapSmooth * mask.  ``blob_peaks_cc`` is the
-connected-component form the GPU kernels implement (8-connected component, first
-raster arg-max, reverse raster order of first pixels); the two agree on isolated and
-merged convex bumps and differ for ring blobs (extra hole keypoint) and for shapes
-fillConvexPoly under-fills -- known answers in tests/test_oracle_v1.py.
+scan fill, first raster maximum of mapSmooth * mask.  The GPU kernels implement
+these literal semantics too (decode_v1.hip, K-B) and are tested against ``blob_peaks``.
+``blob_peaks_cc`` is the connected-component short form (8-connected component,
+first raster arg-max, reverse raster order of first pixels): equal to the literal
+form for every blob with exactly one mask run per row -- the case the GPU kernel
+short-cuts -- and different for ring blobs (extra hole keypoint) and for shapes
+fillConvexPoly under-fills; known answers in tests/test_oracle_v1.py.
 
 np.dot(paf_interp, d_ij) (utils.py:97) is restated as a0*d0 + a1*d1 in float64
 (two products, one add, no FMA): BLAS's internal rounding is not specified.
@@ -101,11 +103,11 @@ def gaussian3(m):
 
 
 def blob_peaks_cc(prob_map, threshold):
-    """getKeypoints (utils.py:9-23) in the simplified form the GPU kernels implement: a blob = an 8-connected
-    component of the mask, its keypoint = the first raster arg-max of the smoothed map over the component, blobs in
-    reverse raster order of their first pixel.  Equal to the literal form (blob_peaks) whenever every blob is free
-    of holes and its arg-max lies inside the polygon fillConvexPoly paints -- true for isolated, roughly convex
-    bumps; see tests/test_oracle_v1.py for the ring / L-shape / merged-people cases where the two differ."""
+    """getKeypoints (utils.py:9-23) in connected-component form: a blob = an 8-connected component of the mask,
+    its keypoint = the first raster arg-max of the smoothed map over the component, blobs in reverse raster order
+    of their first pixel.  Equal to the literal form (blob_peaks) whenever every blob has exactly one mask run per
+    row (then it has no hole and fillConvexPoly paints exactly its pixels) -- the short cut the GPU kernel takes
+    for such maps; see tests/test_oracle_v1.py for the ring / L-shape / merged-people cases where the two differ."""
     from scipy import ndimage
     smooth = gaussian3(prob_map)
     mask = smooth > f32(threshold)                          # fp32 compare (utils.py:11)
@@ -454,12 +456,12 @@ def get_personwise_keypoints(valid_pairs, invalid_pairs, keypoints_list, body_pa
 
 
 def postprocess_multi(prediction, body_parts, pose_pairs, mapidx, image_width, image_height, conf_thres=0.1,
-                      return_intermediates=False, blobs="cc"):
+                      return_intermediates=False, blobs="opencv"):
     """PyOpenPoseOpenCV.postprocess_multi (skeleton.py:102-154).
 
     prediction f32 [1,C,hs,ws] -> (keypoints_list f64 [K,3], personwise list of f64 [len(body_parts)]).
-    blobs: "opencv" = getKeypoints literally (outer + hole contours, fillConvexPoly), "cc" = the connected-component
-    form the GPU kernels implement (see blob_peaks_cc for when the two agree)."""
+    blobs: "opencv" = getKeypoints literally (outer + hole contours, fillConvexPoly); "cc" = the connected-component
+    short form (see blob_peaks_cc for when the two agree), kept to show that a scene exercises the difference."""
     prediction = np.asarray(prediction, f32)
     keypoint_id = 0
     keypoints_list = np.zeros((0, 3))

@@ -261,6 +261,169 @@ __global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------
+// Literal getKeypoints for blobs that are not "simple" (utils.py:14-22 = cv2.findContours(RETR_TREE,
+// CHAIN_APPROX_SIMPLE) + cv2.fillConvexPoly + minMaxLoc; oracle: decode_v1.py blob_peaks / find_contours_tree /
+// fill_convex_poly, which state the OpenCV sources).
+//
+// A blob with exactly ONE run of mask pixels in each of its rows has no hole, and fillConvexPoly paints exactly
+// its pixels: both edge walkers follow a y-monotone boundary chain whose vertical and diagonal pieces they hit
+// exactly, and the horizontal pieces are outline pixels.  For such blobs -- every isolated bump -- the connected
+// component's first raster maximum IS the reference's keypoint and nothing below runs.  Every other blob (several
+// runs in a row: U shapes, rings, people merged side by side) goes through the literal algorithm on the run-length
+// representation: Suzuki-Abe border following as OpenCV codes it (pixel tests = lookups in the row's runs), hole
+// borders found at run ends that no earlier trace has "right-marked", the polygon's outline + two-walker scan
+// fill, the maximum of the smoothed map over what was painted (whole runs contribute their stored maximum,
+// partially covered runs and outline pixels are re-evaluated pixel by pixel with K-A's arithmetic).
+// ---------------------------------------------------------------------------
+#define V1_VCAP 4096        // vertices of one contour
+#define V1_TRACE_CAP 262144 // border pixels of one contour (runaway guard)
+
+struct V1Rows {
+  const V1Run* R;
+  const int* byrow;
+  const int* rowoff;
+  int W, H;
+};
+
+// index of the run that holds pixel (x, y), -1 for a background / outside pixel
+__device__ __forceinline__ int v1_run_at(const V1Rows& g, int x, int y) {
+  if (x < 0 || y < 0 || x >= g.W || y >= g.H) return -1;
+  for (int j = g.rowoff[y]; j < g.rowoff[y + 1]; j++) {
+    const int o = g.byrow[j];
+    if (g.R[o].xs <= x && x <= g.R[o].xe) return o;
+  }
+  return -1;
+}
+
+// the smoothed map at one pixel, with the operations of v1_runs_kernel (resize, row pass, column pass)
+__device__ float v1_smooth_at(const float* src, int hs, int ws, int W, int H, int x, int y) {
+  float t[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const LinX cy = lin_y(reflect101(y - 1 + r, H), H, hs);
+    float h[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) h[c] = resize_tab(src, ws, lin_x(reflect101(x - 1 + c, W), W, ws), cy);
+    t[r] = h[1] * 0.5f + (h[0] + h[2]) * 0.25f;
+  }
+  return t[1] * 0.5f + (t[0] + t[2]) * 0.25f;
+}
+
+__device__ __forceinline__ unsigned long long v1_key(float v, int x, int y, int W) {
+  return ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - (unsigned)(y * W + x));
+}
+
+// icvFetchContour on the runs: follows the border that starts at (x0, y0), writes the CHAIN_APPROX_SIMPLE vertices
+// and records, for every border pixel whose right neighbour the search examined and found empty, the contour id on
+// that pixel's run (the "-nbd" mark of the library: only run ends can carry it).  Returns the vertex count, -1 on
+// overflow.  One thread.
+__device__ int v1_trace(const V1Rows& g, int x0, int y0, bool is_hole, unsigned short cid, short2* verts,
+                        unsigned short* mark) {
+  const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+  const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+  int n = 0;
+  int s_end = is_hole ? 0 : 4, s = s_end;
+  int i1x, i1y;
+  do {
+    s = (s - 1) & 7;
+    i1x = x0 + DX[s];
+    i1y = y0 + DY[s];
+  } while (v1_run_at(g, i1x, i1y) < 0 && s != s_end);
+  if (s == s_end) {  // single pixel
+    mark[v1_run_at(g, x0, y0)] = cid;
+    verts[0] = make_short2((short)x0, (short)y0);
+    return 1;
+  }
+  int i3x = x0, i3y = y0, ptx = x0, pty = y0, prev_s = s ^ 4;
+  for (int guard = 0; guard < V1_TRACE_CAP; guard++) {
+    s_end = s;
+    int i4x = i3x, i4y = i3y;
+    while (s < 15) {
+      s++;
+      i4x = i3x + DX[s & 7];
+      i4y = i3y + DY[s & 7];
+      if (v1_run_at(g, i4x, i4y) >= 0) break;
+    }
+    s &= 7;
+    if ((unsigned)(s - 1) < (unsigned)s_end) mark[v1_run_at(g, i3x, i3y)] = cid;
+    if (s != prev_s) {
+      if (n >= V1_VCAP) return -1;
+      verts[n++] = make_short2((short)ptx, (short)pty);
+      prev_s = s;
+    }
+    ptx += DX[s];
+    pty += DY[s];
+    if (i4x == x0 && i4y == y0 && i3x == i1x && i3y == i1y) return n;
+    i3x = i4x;
+    i3y = i4y;
+    s = (s + 4) & 7;
+  }
+  return -1;
+}
+
+// FillConvexPoly's two edge walkers (lineType 8, shift 0): the span [l, r] painted in every row from the polygon's
+// top row on; rows the loop never reaches keep an empty span.  Returns the top row.  One thread.
+__device__ int v1_fill_spans(const short2* v, int n, int W, int H, short2* span, int* rows_out) {
+  const long long XY_ONE = 1 << 16;
+  int xmin = v[0].x, xmax = v[0].x, ymin = v[0].y, ymax = v[0].y, imin = 0;
+  for (int i = 0; i < n; i++) {
+    if (v[i].y < ymin) {
+      ymin = v[i].y;
+      imin = i;
+    }
+    ymax = ymax > v[i].y ? ymax : v[i].y;
+    xmax = xmax > v[i].x ? xmax : v[i].x;
+    xmin = xmin < v[i].x ? xmin : v[i].x;
+  }
+  const int nrows = ymax - ymin + 1;
+  *rows_out = nrows;
+  for (int r = 0; r < nrows; r++) span[r] = make_short2(1, 0);
+  if (n < 3 || xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return ymin;
+  ymax = ymax < H - 1 ? ymax : H - 1;
+  int edges = n;
+  int e_idx[2] = {imin, imin}, e_ye[2] = {ymin, ymin}, e_di[2] = {1, n - 1};
+  long long e_x[2] = {-XY_ONE, -XY_ONE}, e_dx[2] = {0, 0};
+  int y = ymin;
+  do {
+    for (int i = 0; i < 2; i++) {
+      if (y >= e_ye[i]) {
+        int idx0 = e_idx[i];
+        const int di = e_di[i];
+        int idx = idx0 + di;
+        if (idx >= n) idx -= n;
+        for (; edges-- > 0;) {
+          const int ty = v[idx].y;
+          if (ty > y) {
+            const long long xs = (long long)v[idx0].x << 16, xe = (long long)v[idx].x << 16;
+            e_ye[i] = ty;
+            e_dx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));   // C division: towards zero, as the library's
+            e_x[i] = xs;
+            e_idx[i] = idx;
+            break;
+          }
+          idx0 = idx;
+          idx += di;
+          if (idx >= n) idx -= n;
+        }
+      }
+    }
+    if (edges < 0) break;
+    if (y >= 0) {
+      const int left = e_x[0] > e_x[1] ? 1 : 0, right = 1 - left;
+      int xx1 = (int)((e_x[left] + (XY_ONE >> 1)) >> 16), xx2 = (int)((e_x[right] + (XY_ONE >> 1)) >> 16);
+      if (xx2 >= 0 && xx1 < W) {
+        xx1 = xx1 < 0 ? 0 : xx1;
+        xx2 = xx2 >= W ? W - 1 : xx2;
+        span[y - ymin] = make_short2((short)xx1, (short)xx2);
+      }
+    }
+    e_x[0] += e_dx[0];
+    e_x[1] += e_dx[1];
+  } while (++y <= ymax);
+  return ymin;
+}
+
+// ---------------------------------------------------------------------------
 // K-B: blobs from runs.  grid (n_parts, B), block 256
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int uf_find(volatile int* parent, int i) {
@@ -305,7 +468,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   }
   const V1Run* R = runs + ((size_t)b * n_parts + part) * run_cap;
   unsigned long long* best = ws_best + ((size_t)b * n_parts + part) * run_cap;
-  int* first = ws_first + ((size_t)b * n_parts + part) * run_cap;
+  int* first = ws_first + ((size_t)b * n_parts + part) * run_cap * 3;
   int* parent = ismem;              // n
   int* byrow = parent + run_cap;    // n: run indices grouped by row
   int* rowoff = byrow + run_cap;    // H + 2
@@ -321,6 +484,8 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
     atomicAdd(&rowoff[R[i].y + 1], 1);
     best[i] = 0ull;
     first[i] = 0x7fffffff;
+    first[run_cap + i] = -1;      // last row of the blob rooted here
+    first[2 * run_cap + i] = 0;   // its number of runs
   }
   __threadfence();  // the initial values must be in L2 before any atomic of step 3 lands there
   __syncthreads();
@@ -369,13 +534,19 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
       }
   }
   __syncthreads();
-  // per-blob first-raster maximum and first pixel
+  // per-blob first-raster maximum, first pixel, last row and number of (seam-merged) runs
+  int* ymaxv = first + run_cap;
+  int* nrunv = first + 2 * run_cap;
   for (int i = tid; i < n; i += 256) {
     const int root = uf_find(parent, i);
     const V1Run r = R[i];
     const unsigned pos = (unsigned)(r.y * W + r.bx);
     atomicMax(&best[root], ((unsigned long long)__float_as_uint(r.best) << 32) | (0xffffffffu - pos));
     atomicMin(&first[root], r.y * W + r.xs);
+    atomicMax(&ymaxv[root], r.y);
+    bool cont = false;  // continues a run cut at a tile seam
+    for (int j = rowoff[r.y]; j < rowoff[r.y + 1]; j++) cont |= R[byrow[j]].xe + 1 == r.xs;
+    if (!cont) atomicAdd(&nrunv[root], 1);
     if (root == i) {
       const int s = atomicAdd(&s_nroot, 1);
       if (s < kp_cap) roots[s] = i; else *overflow = 1;
@@ -384,21 +555,242 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   __threadfence_block();
   __syncthreads();
   const int nr = s_nroot < kp_cap ? s_nroot : kp_cap;
-  // findContours list order: reverse raster order of each blob's first pixel
+  auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
+  // blobs with more than one run in some row need the literal contour + fill (see the helpers' header)
+  __shared__ int s_nirr;
+  if (tid == 0) s_nirr = 0;
+  __syncthreads();
   for (int i = tid; i < nr; i += 256) {
     const int me = roots[i];
-    const int fp = __hip_atomic_load(&first[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int rank = 0;
-    for (int j = 0; j < nr; j++)
-      rank += __hip_atomic_load(&first[roots[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > fp;
-    const unsigned long long k = __hip_atomic_load(&best[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned pos = 0xffffffffu - (unsigned)(k & 0xffffffffu);
-    const int y = pos / W, x = pos - y * W;
-    out[rank * 3 + 0] = (float)x;
-    out[rank * 3 + 1] = (float)y;
-    out[rank * 3 + 2] = resize_at(net_out + ((size_t)b * C + part) * hs * ws, hs, ws, W, H, x, y);
+    if (ld(&nrunv[me]) != ld(&ymaxv[me]) - ld(&first[me]) / W + 1) atomicAdd(&s_nirr, 1);
   }
-  if (tid == 0) *out_n = nr;
+  __syncthreads();
+  if (s_nirr == 0) {
+    // findContours list order: reverse raster order of each blob's first pixel
+    for (int i = tid; i < nr; i += 256) {
+      const int me = roots[i];
+      const int fp = ld(&first[me]);
+      int rank = 0;
+      for (int j = 0; j < nr; j++) rank += ld(&first[roots[j]]) > fp;
+      const unsigned long long k = __hip_atomic_load(&best[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned pos = 0xffffffffu - (unsigned)(k & 0xffffffffu);
+      const int y = pos / W, x = pos - y * W;
+      out[rank * 3 + 0] = (float)x;
+      out[rank * 3 + 1] = (float)y;
+      out[rank * 3 + 2] = resize_at(plane, hs, ws, W, H, x, y);
+    }
+    if (tid == 0) *out_n = nr;
+    return;
+  }
+
+  // ---- literal path ------------------------------------------------------------------------------------------
+  auto up = [](void* p_, size_t a) { return (char*)(((size_t)p_ + a - 1) & ~(a - 1)); };
+  unsigned long long* c_key = (unsigned long long*)up(roots + kp_cap, 8);  // arg-max key per contour
+  int* c_disc = (int*)(c_key + kp_cap);          // discovery position (raster index of the border's start)
+  short* c_par = (short*)(c_disc + kp_cap);      // parent contour, -1 = the frame
+  short* c_ord = c_par + kp_cap;                 // output order
+  unsigned char* c_hole = (unsigned char*)(c_ord + kp_cap);
+  unsigned short* mark = (unsigned short*)up(c_hole + kp_cap, 2);   // per run: contour id + 1 of the trace that
+  short2* verts = (short2*)up(mark + run_cap, 4);                   // right-marked its last pixel
+  short2* span = verts + V1_VCAP;                                   // H
+  __shared__ unsigned long long s_key;
+  __shared__ int s_nv, s_top, s_rows, s_ncont, s_go, s_hx, s_hy;
+  const V1Rows g = {R, byrow, rowoff, W, H};
+  for (int i = tid; i < n; i += 256) mark[i] = 0;
+  if (tid == 0) s_ncont = nr;
+  __syncthreads();
+  // maximum of the smoothed map over what fillConvexPoly paints for the contour in verts[0 .. s_nv)
+  auto paint_max = [&]() {
+    const int nv = s_nv, top = s_top, nrows = s_rows;
+    for (int e = tid; e < nv; e += 256) {          // outline: the polygon's edges are straight 8-connected runs
+      const short2 a = verts[e == 0 ? nv - 1 : e - 1], c = verts[e];
+      const int dx = c.x - a.x, dy = c.y - a.y;
+      const int steps = abs(dx) > abs(dy) ? abs(dx) : abs(dy);
+      const int sx = (dx > 0) - (dx < 0), sy = (dy > 0) - (dy < 0);
+      for (int t = 0; t <= steps; t++) {
+        const int x = a.x + t * sx, y = a.y + t * sy;
+        atomicMax(&s_key, v1_key(v1_smooth_at(plane, hs, ws, W, H, x, y), x, y, W));
+      }
+    }
+    for (int r = tid; r < nrows; r += 256) {       // scan fill: runs of ANY blob under the span count, as in cv2
+      const short2 sp = span[r];
+      if (sp.x > sp.y) continue;
+      const int y = top + r;
+      if (y < 0 || y >= H) continue;
+      for (int j = rowoff[y]; j < rowoff[y + 1]; j++) {
+        const V1Run q = R[byrow[j]];
+        const int lo = sp.x > q.xs ? sp.x : q.xs, hi = sp.y < q.xe ? sp.y : q.xe;
+        if (lo > hi) continue;
+        if (lo == q.xs && hi == q.xe) {
+          atomicMax(&s_key, v1_key(q.best, q.bx, y, W));
+        } else {
+          for (int x = lo; x <= hi; x++) atomicMax(&s_key, v1_key(v1_smooth_at(plane, hs, ws, W, H, x, y), x, y, W));
+        }
+      }
+    }
+  };
+  for (int i = 0; i < nr; i++) {                   // (block-uniform loop)
+    const int me = roots[i];
+    const int fp = ld(&first[me]), y_last = ld(&ymaxv[me]);
+    const bool simple = ld(&nrunv[me]) == y_last - fp / W + 1;
+    if (tid == 0) {
+      c_disc[i] = fp;
+      c_par[i] = -1;
+      c_hole[i] = 0;
+      if (simple) c_key[i] = __hip_atomic_load(&best[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (simple) continue;
+    // outer border: starts at the blob's first raster pixel
+    if (tid == 0) {
+      s_key = 0ull;
+      s_nv = v1_trace(g, fp % W, fp / W, false, (unsigned short)(i + 1), verts, mark);
+      if (s_nv < 0) {
+        *overflow = 1;
+        s_nv = 0;
+        s_rows = 0;
+      } else {
+        int nrows;
+        s_top = v1_fill_spans(verts, s_nv, W, H, span, &nrows);
+        s_rows = nrows;
+      }
+    }
+    __syncthreads();
+    paint_max();
+    __syncthreads();
+    if (tid == 0) c_key[i] = s_key;
+    // hole borders: the blob's run ends, in raster order, that no trace so far has right-marked
+    int cy = fp / W, cx = -1;
+    for (;;) {
+      if (tid == 0) {
+        s_go = 0;
+        for (int y = cy; y <= y_last && !s_go; y++) {
+          int bestx = 0x7fffffff, bestrun = -1;
+          for (int j = rowoff[y]; j < rowoff[y + 1]; j++) {
+            const int o = byrow[j];
+            const int xe = R[o].xe;
+            if ((y == cy && xe <= cx) || xe >= bestx || mark[o] != 0 || uf_find(parent, o) != me) continue;
+            bool cont = false;  // cut at a tile seam: the run goes on, this is not its end
+            for (int j2 = rowoff[y]; j2 < rowoff[y + 1]; j2++) cont |= R[byrow[j2]].xs == xe + 1;
+            if (cont) continue;
+            bestx = xe;
+            bestrun = o;
+          }
+          if (bestrun >= 0) {
+            s_go = 1;
+            s_hx = bestx;
+            s_hy = y;
+          }
+        }
+        if (s_go) {
+          const int c = s_ncont;
+          if (c >= kp_cap) {
+            *overflow = 1;
+            s_go = 0;
+          } else {
+            s_ncont = c + 1;
+            c_disc[c] = s_hy * W + s_hx;         // (discovered one pixel further right; same order among holes)
+            c_par[c] = (short)i;
+            c_hole[c] = 1;
+            s_key = 0ull;
+            s_nv = v1_trace(g, s_hx, s_hy, true, (unsigned short)(c + 1), verts, mark);
+            if (s_nv < 0) {
+              *overflow = 1;
+              s_nv = 0;
+              s_rows = 0;
+            } else {
+              int nrows;
+              s_top = v1_fill_spans(verts, s_nv, W, H, span, &nrows);
+              s_rows = nrows;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (!s_go) break;
+      paint_max();
+      __syncthreads();
+      if (tid == 0) c_key[s_ncont - 1] = s_key;
+      cy = s_hy;
+      cx = s_hx;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  const int nc = s_ncont;
+  if (tid == 0) {
+    // parents of the outer borders (RETR_TREE): the border met last on the first pixel's row = the one that
+    // right-marked the nearest run end to its left; a hole border is the parent itself, an outer border hands
+    // on its own parent.  Resolved in discovery order (a parent is always discovered first).
+    if (nc > nr) {
+      for (int k = 0; k < nr; k++) c_ord[k] = (short)k;
+      for (int a = 1; a < nr; a++) {               // insertion sort by discovery position
+        const short v = c_ord[a];
+        int q = a - 1;
+        while (q >= 0 && c_disc[c_ord[q]] > c_disc[v]) {
+          c_ord[q + 1] = c_ord[q];
+          q--;
+        }
+        c_ord[q + 1] = v;
+      }
+      for (int k = 0; k < nr; k++) {
+        const int X = c_ord[k];
+        const int x0 = c_disc[X] % W, y0 = c_disc[X] / W;
+        int bx = -1, brun = -1;
+        for (int j = rowoff[y0]; j < rowoff[y0 + 1]; j++) {
+          const int o = byrow[j];
+          if (R[o].xe < x0 && R[o].xe > bx) {
+            bx = R[o].xe;
+            brun = o;
+          }
+        }
+        int par = -1;
+        if (brun >= 0) {
+          int Bp = (int)mark[brun] - 1;
+          if (Bp < 0) {                            // a simple blob: its only border is its outer one
+            const int rt = uf_find(parent, brun);
+            for (int q = 0; q < nr; q++)
+              if (roots[q] == rt) Bp = q;
+          }
+          par = c_hole[Bp] ? Bp : c_par[Bp];
+        }
+        c_par[X] = (short)par;
+      }
+    }
+    // list order of cvTreeToNodeSeq: a node, its children, its next sibling; siblings latest-discovered first
+    int emitted = 0, sp_ = 0;
+    short* stack = (short*)span;                    // (the span table is free now)
+    auto push_children = [&](int node) {
+      // ascending discovery onto the stack, so the latest is popped first
+      int last = -1;
+      for (;;) {
+        int pick = -1;
+        for (int c = 0; c < nc; c++)
+          if (c_par[c] == node && c_disc[c] > last && (pick < 0 || c_disc[c] < c_disc[pick])) pick = c;
+        if (pick < 0) break;
+        stack[sp_++] = (short)pick;
+        last = c_disc[pick];
+      }
+    };
+    push_children(-1);
+    while (sp_ > 0) {
+      const int c = stack[--sp_];
+      c_ord[emitted++] = (short)c;
+      push_children(c);
+    }
+    s_ncont = emitted;
+  }
+  __syncthreads();
+  const int total = s_ncont;
+  for (int k = tid; k < total; k += 256) {
+    const unsigned long long key = c_key[c_ord[k]];
+    const unsigned pos = 0xffffffffu - (unsigned)(key & 0xffffffffu);
+    const int y = pos / W, x = pos - y * W;
+    out[k * 3 + 0] = (float)x;
+    out[k * 3 + 1] = (float)y;
+    out[k * 3 + 2] = resize_at(plane, hs, ws, W, H, x, y);
+  }
+  if (tid == 0) *out_n = total;
 }
 
 // ---------------------------------------------------------------------------
@@ -567,7 +959,7 @@ int ph_v1_sizes(const V1Model& m, int B, int W, int H, const V1Caps& c, V1Sizes*
   s->n_runs = (size_t)B * m.n_parts * sizeof(int);
   s->runs = (size_t)B * m.n_parts * c.run_cap * sizeof(V1Run);
   s->ws_best = (size_t)B * m.n_parts * c.run_cap * sizeof(unsigned long long);
-  s->ws_first = (size_t)B * m.n_parts * c.run_cap * sizeof(int);
+  s->ws_first = (size_t)B * m.n_parts * c.run_cap * 3 * sizeof(int);   // first pixel, last row, run count
   s->kps = (size_t)B * m.n_parts * c.kp_cap * 3 * sizeof(float);
   s->n_kps = (size_t)B * m.n_parts * sizeof(int);
   s->pairs = (size_t)B * m.n_limbs * c.kp_cap * 3 * sizeof(double);
@@ -594,7 +986,9 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   }
   const size_t ldsA = ((size_t)hs * ws + (size_t)(V1_TILE_H + 2) * (V1_TILE_W + 2) +
                        (size_t)(V1_TILE_H + 2) * V1_TILE_W + (size_t)V1_TILE_H * V1_TILE_W) * 4;
-  const size_t ldsB = ((size_t)2 * c.run_cap + H + 2 + c.kp_cap) * 4;
+  // K-B: union-find tables + (literal path) contour table, run marks, vertex list, span table
+  const size_t ldsB = ((size_t)2 * c.run_cap + H + 2 + c.kp_cap) * 4 + 8 + (size_t)c.kp_cap * (8 + 4 + 2 + 2 + 1) + 8 +
+                      (size_t)c.run_cap * 2 + (size_t)V1_VCAP * 4 + (size_t)H * 4 + 16;
   const size_t ldsC = (size_t)2 * hs * ws * 4;
   const size_t ldsD = (size_t)c.person_cap * (m.n_parts + 1) * 8;
   const size_t lim = 160 * 1024 - 8192;  // static __shared__ tables sit beside the dynamic region

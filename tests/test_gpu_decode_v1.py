@@ -15,7 +15,10 @@ BODY_PARTS, POSE_PAIRS = get_body_parts_and_pose_pairs("COCO")
 
 def _oracle(pred, W, H, thr=0.1):
     from oracle import decode_v1
-    return decode_v1.postprocess_multi(pred, BODY_PARTS, POSE_PAIRS, MAPIDX, W, H, thr, return_intermediates=True)
+    # blobs="opencv": the literal findContours(RETR_TREE) + fillConvexPoly walk of
+    # getKeypoints (utils.py:14-22), holes and under-filled concave blobs included
+    return decode_v1.postprocess_multi(pred, BODY_PARTS, POSE_PAIRS, MAPIDX, W, H, thr,
+                                       return_intermediates=True, blobs="opencv")
 
 
 def _check(got, ref):
@@ -74,6 +77,81 @@ def test_blob_edge_cases(engine):
     ref = _oracle(pred, 656, 368)
     _check(got[0], ref)
     assert ref[0].shape[0] >= 4
+
+
+def _shape_scene():
+    """Heat maps whose blobs are NOT one run per row: rings (hole contours are
+    keypoints too, utils.py:17), a ring with an island in its hole (RETR_TREE
+    nesting order), U / C / S / X shapes that fillConvexPoly under-fills, two
+    holes in one blob, a ring on the image border."""
+    pred = np.zeros((1, 57, 46, 82), np.float32)
+    pred[0, 0, 5:10, 5:10] = 0.9; pred[0, 0, 6:9, 6:9] = 0.0
+    pred[0, 1, 10:21, 10:21] = 0.8; pred[0, 1, 12:19, 12:19] = 0.0; pred[0, 1, 15, 15] = 0.95
+    pred[0, 2, 20:30, 40] = 0.5; pred[0, 2, 29, 40:50] = 0.5; pred[0, 2, 20:30, 49] = 0.6; pred[0, 2, 21, 49] = 0.9
+    pred[0, 3, 5, 30:38] = 0.7; pred[0, 3, 5:15, 37] = 0.7; pred[0, 3, 14, 30:38] = 0.75
+    pred[0, 4, 30, 10:20] = 0.6; pred[0, 4, 30:36, 10] = 0.6; pred[0, 4, 35, 10:20] = 0.6
+    pred[0, 4, 35:41, 19] = 0.6; pred[0, 4, 40, 10:20] = 0.65
+    pred[0, 5, 5:12, 50:63] = 0.8; pred[0, 5, 7:10, 52:55] = 0.0; pred[0, 5, 7:10, 58:61] = 0.0; pred[0, 5, 8, 70] = 0.9
+    for i in range(8):
+        pred[0, 6, 20 + i, 60 + i] = 0.7
+    pred[0, 7, 0:6, 0:6] = 0.8; pred[0, 7, 2:4, 2:4] = 0.0
+    for i in range(10):
+        pred[0, 8, 30 + i, 60 + i] = 0.7
+        pred[0, 8, 39 - i, 60 + i] = 0.7
+    return pred
+
+
+@pytest.mark.parametrize("W,H", [(656, 368), (480, 480), (1280, 720)])
+def test_literal_contours_shapes(engine, W, H):
+    from oracle import decode_v1
+    pred = _shape_scene()
+    engine.set_net_out(pred)
+    got = engine.decode_v1(BODY_PARTS, POSE_PAIRS, MAPIDX, 1, W, H, 0.1)
+    ref = _oracle(pred, W, H)
+    _check(got[0], ref)
+    # the scene really exercises the literal path: the connected-component
+    # arg-max rule gives a different keypoint list
+    cc = decode_v1.postprocess_multi(pred, BODY_PARTS, POSE_PAIRS, MAPIDX, W, H, 0.1,
+                                     return_intermediates=True, blobs="cc")
+    assert cc[0].shape != ref[0].shape
+
+
+def test_literal_contours_crowd(engine):
+    """60 people at 656x368: merged blobs with several runs per row on some parts."""
+    preds = np.stack([synth.synth_net_output(4, 60, COCO_18, 46, 82), synth.synth_net_output(5, 45, COCO_18, 46, 82)])
+    engine.set_net_out(preds)
+    got = engine.decode_v1(BODY_PARTS, POSE_PAIRS, MAPIDX, 2, 656, 368, 0.1, kp_cap=128, person_cap=256)
+    for b in range(2):
+        _check(got[b], _oracle(preds[b:b + 1], 656, 368))
+
+
+def _noise_scene(seed, parts, level, hs=46, ws=82):
+    """Smoothed white noise on the first `parts` heat maps: ragged blobs with
+    holes, islands in holes, spirals - whatever the threshold cuts out."""
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((parts, hs, ws)).astype(np.float32)
+    for _ in range(2):
+        f = (np.roll(f, 1, 1) + 2 * f + np.roll(f, -1, 1)) / 4
+        f = (np.roll(f, 1, 2) + 2 * f + np.roll(f, -1, 2)) / 4
+    pred = np.zeros((1, 57, hs, ws), np.float32)
+    pred[0, :parts] = f / f.std() * 0.2 + level
+    return pred
+
+
+@pytest.mark.parametrize("seed,level,W,H,hs,ws", [
+    (7, 0.05, 656, 368, 46, 82), (8, 0.0, 656, 368, 46, 82), (9, 0.12, 656, 368, 46, 82), (10, 0.25, 480, 480, 46, 82),
+    (11, 0.1, 1280, 720, 23, 41), (12, 0.3, 333, 247, 46, 82), (13, 0.08, 1920, 1080, 16, 28),
+])
+def test_literal_contours_noise(engine, seed, level, W, H, hs, ws):
+    """Arbitrary mask topology (tens of contours per part, contours of up to a
+    few thousand vertices): list order, hole borders, nesting and fill all have
+    to agree with the literal walk, keypoint by keypoint."""
+    pred = _noise_scene(seed, 6, level, hs, ws)   # (coarser maps at the large sizes: the 8192-run capacity)
+    engine.set_net_out(pred)
+    got = engine.decode_v1(BODY_PARTS, POSE_PAIRS, MAPIDX, 1, W, H, 0.1)
+    ref = _oracle(pred, W, H)
+    _check(got[0], ref)
+    assert ref[0].shape[0] > 30
 
 
 def test_capacity_error(engine):
