@@ -214,7 +214,7 @@ static void free_v2(ph_ctx* c) {
 
 static void free_v1(ph_ctx* c) {
   void* ptrs[] = {c->v1.n_runs, c->v1.runs,    c->v1.ws_best, c->v1.ws_first,  c->v1.kps,     c->v1.n_kps,
-                  c->v1.pairs,  c->v1.n_pairs, c->v1.persons, c->v1.n_persons, c->v1.overflow};
+                  c->v1.pairs,  c->v1.n_pairs, c->v1.persons, c->v1.n_persons, c->v1.overflow, c->v1.ws_verts};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   c->v1 = V1Buffers{};
@@ -1200,6 +1200,7 @@ int ph_decode_v1(ph_ctx* c, const ph_v1_model* m, int B, int W0, int H0, float c
     PH_CHECK(hipMalloc(&c->v1.runs, c->v1sz.runs));
     PH_CHECK(hipMalloc(&c->v1.ws_best, c->v1sz.ws_best));
     PH_CHECK(hipMalloc(&c->v1.ws_first, c->v1sz.ws_first));
+    PH_CHECK(hipMalloc(&c->v1.ws_verts, c->v1sz.ws_verts));
     PH_CHECK(hipMalloc(&c->v1.kps, c->v1sz.kps));
     PH_CHECK(hipMalloc(&c->v1.n_kps, c->v1sz.n_kps));
     PH_CHECK(hipMalloc(&c->v1.pairs, c->v1sz.pairs));

@@ -5,6 +5,8 @@
 
 #define V1_MAX_PARTS 32
 #define V1_MAX_LIMBS 32
+// contour vertices one (frame, part) may hold at a time in the literal blob walk
+#define V1_VERT_POOL(run_cap) (8 * (run_cap))
 
 struct V1Run {
   int y, xs, xe;  // row, first and last column of a run of mask pixels
@@ -24,7 +26,7 @@ struct V1Caps {
 };
 
 struct V1Sizes {
-  size_t n_runs, runs, ws_best, ws_first, kps, n_kps, pairs, n_pairs, persons, n_persons;
+  size_t n_runs, runs, ws_best, ws_first, ws_verts, kps, n_kps, pairs, n_pairs, persons, n_persons;
 };
 
 struct V1Buffers {
@@ -32,6 +34,7 @@ struct V1Buffers {
   V1Run* runs;
   unsigned long long* ws_best;
   int* ws_first;
+  short2* ws_verts;
   float* kps;
   int* n_kps;
   double* pairs;

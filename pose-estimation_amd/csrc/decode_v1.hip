@@ -8,15 +8,17 @@
 //   K-A  per 16x256 tile: bilinear resize -> 3x3 Gaussian -> threshold -> row
 //        runs of the mask with their first-raster maxima (tiles whose source
 //        cells are all below threshold are skipped);
-//   K-B  per (frame, part): runs bucketed by row in LDS, lock-free union-find
-//        over touching runs (8-connectivity) = the blobs cv2.findContours
-//        traces, per-blob arg-max, findContours list order;
+//   K-B  per (frame, part): runs sorted by (row, column) in LDS, lock-free
+//        union-find over touching runs (8-connectivity) = the blobs
+//        cv2.findContours traces; a blob with one run per row gives its
+//        arg-max, every other blob is walked literally (border following,
+//        hole borders, fillConvexPoly) by a group of 8 lanes; RETR_TREE
+//        list order;
 //   K-C  per (frame, limb): 10-sample nearest-pixel PAF line integral in fp64,
 //        per-A arg-max, ordered compaction;
 //   K-D  per frame: person assembly in LDS.
 // Bit-exact against oracle/decode_v1.py (same IEEE operations, same order;
-// built with -ffp-contract=off).  Stated deviations from literal cv2 blob
-// semantics are listed in that file's header.
+// built with -ffp-contract=off).
 #include "common.h"
 #include "decode_v1.h"
 
@@ -270,29 +272,32 @@ __global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __
 // exactly, and the horizontal pieces are outline pixels.  For such blobs -- every isolated bump -- the connected
 // component's first raster maximum IS the reference's keypoint and nothing below runs.  Every other blob (several
 // runs in a row: U shapes, rings, people merged side by side) goes through the literal algorithm on the run-length
-// representation: Suzuki-Abe border following as OpenCV codes it (pixel tests = lookups in the row's runs), hole
+// representation, ONE THREAD PER BLOB (blobs are independent: a border only touches pieces of its own blob):
+// Suzuki-Abe border following as OpenCV codes it (pixel tests = binary searches in the row's sorted pieces), hole
 // borders found at run ends that no earlier trace has "right-marked", the polygon's outline + two-walker scan
-// fill, the maximum of the smoothed map over what was painted (whole runs contribute their stored maximum,
-// partially covered runs and outline pixels are re-evaluated pixel by pixel with K-A's arithmetic).
+// fill, the maximum of the smoothed map over what was painted (a piece whose stored maximum lies under the paint
+// contributes it directly; a piece whose maximum cannot beat the running one is skipped; only what is left is
+// re-evaluated pixel by pixel with K-A's arithmetic).
 // ---------------------------------------------------------------------------
-#define V1_VCAP 4096        // vertices of one contour
 #define V1_TRACE_CAP 262144 // border pixels of one contour (runaway guard)
 
-struct V1Rows {
-  const V1Run* R;
-  const int* byrow;
-  const int* rowoff;
+struct V1Grid {
+  const short2* srun;  // LDS: mask pieces {xs, xe}; rows ascending, xs ascending within a row (a run that crosses
+  const int* rowoff;   //      a K-A tile seam is two touching pieces); row y = [rowoff[y], rowoff[y+1])
   int W, H;
 };
 
-// index of the run that holds pixel (x, y), -1 for a background / outside pixel
-__device__ __forceinline__ int v1_run_at(const V1Rows& g, int x, int y) {
+// sorted position of the piece that holds pixel (x, y), -1 for a background / outside pixel
+__device__ __forceinline__ int v1_piece_at(const V1Grid& g, int x, int y) {
   if (x < 0 || y < 0 || x >= g.W || y >= g.H) return -1;
-  for (int j = g.rowoff[y]; j < g.rowoff[y + 1]; j++) {
-    const int o = g.byrow[j];
-    if (g.R[o].xs <= x && x <= g.R[o].xe) return o;
+  const int r0 = g.rowoff[y];
+  int lo = r0, hi = g.rowoff[y + 1];
+  while (lo < hi) {  // first piece with xs > x
+    const int mid = (lo + hi) >> 1;
+    if (g.srun[mid].x <= x) lo = mid + 1;
+    else hi = mid;
   }
-  return -1;
+  return (lo > r0 && g.srun[lo - 1].y >= x) ? lo - 1 : -1;
 }
 
 // the smoothed map at one pixel, with the operations of v1_runs_kernel (resize, row pass, column pass)
@@ -313,114 +318,237 @@ __device__ __forceinline__ unsigned long long v1_key(float v, int x, int y, int 
   return ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - (unsigned)(y * W + x));
 }
 
-// icvFetchContour on the runs: follows the border that starts at (x0, y0), writes the CHAIN_APPROX_SIMPLE vertices
-// and records, for every border pixel whose right neighbour the search examined and found empty, the contour id on
-// that pixel's run (the "-nbd" mark of the library: only run ends can carry it).  Returns the vertex count, -1 on
-// overflow.  One thread.
-__device__ int v1_trace(const V1Rows& g, int x0, int y0, bool is_hole, unsigned short cid, short2* verts,
-                        unsigned short* mark) {
-  const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
-  const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-  int n = 0;
-  int s_end = is_hole ? 0 : 4, s = s_end;
-  int i1x, i1y;
-  do {
-    s = (s - 1) & 7;
-    i1x = x0 + DX[s];
-    i1y = y0 + DY[s];
-  } while (v1_run_at(g, i1x, i1y) < 0 && s != s_end);
-  if (s == s_end) {  // single pixel
-    mark[v1_run_at(g, x0, y0)] = cid;
-    verts[0] = make_short2((short)x0, (short)y0);
-    return 1;
-  }
-  int i3x = x0, i3y = y0, ptx = x0, pty = y0, prev_s = s ^ 4;
-  for (int guard = 0; guard < V1_TRACE_CAP; guard++) {
-    s_end = s;
-    int i4x = i3x, i4y = i3y;
-    while (s < 15) {
-      s++;
-      i4x = i3x + DX[s & 7];
-      i4y = i3y + DY[s & 7];
-      if (v1_run_at(g, i4x, i4y) >= 0) break;
+// the 8 neighbour offsets, E NE N NW W SW S SE (y grows downwards), as 2-bit fields: no table in memory
+__device__ __forceinline__ int v1_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }
+__device__ __forceinline__ int v1_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }
+
+// One thread's contour vertices: a block of the (frame, part)'s pool that grows by doubling -- in place while it is
+// the pool's last block, else by moving -- and is kept for the thread's next contour.
+struct V1Verts {
+  short2* pool;
+  int* used;      // LDS: entries of the pool handed out
+  int pool_cap;
+  int base, cap;
+  __device__ bool push(int n, short2 v) {
+    if (n == cap) {
+      const int want = cap ? 2 * cap : 64;
+      if (cap && atomicCAS(used, base + cap, base + want) == base + cap) {
+        if (base + want > pool_cap) return false;
+      } else {
+        const int nb = atomicAdd(used, want);
+        if (nb + want > pool_cap) return false;
+        for (int i = 0; i < n; i++) pool[nb + i] = pool[base + i];
+        base = nb;
+      }
+      cap = want;
     }
-    s &= 7;
-    if ((unsigned)(s - 1) < (unsigned)s_end) mark[v1_run_at(g, i3x, i3y)] = cid;
-    if (s != prev_s) {
-      if (n >= V1_VCAP) return -1;
-      verts[n++] = make_short2((short)ptx, (short)pty);
-      prev_s = s;
-    }
-    ptx += DX[s];
-    pty += DY[s];
-    if (i4x == x0 && i4y == y0 && i3x == i1x && i3y == i1y) return n;
-    i3x = i4x;
-    i3y = i4y;
-    s = (s + 4) & 7;
+    pool[base + n] = v;
+    return true;
   }
-  return -1;
+};
+
+// A blob is walked by a GROUP of 8 adjacent lanes (control flow uniform within the group): the 8 neighbour probes
+// of a border step, the rows of the fill, the edges of the outline and the rows of the hole search are spread over
+// the lanes; lane 0 of the group owns the stores.
+__device__ __forceinline__ unsigned v1_gballot(bool p, int lane) {
+  return (unsigned)((__ballot(p) >> (lane & 56)) & 0xffull);
 }
 
-// FillConvexPoly's two edge walkers (lineType 8, shift 0): the span [l, r] painted in every row from the polygon's
-// top row on; rows the loop never reaches keep an empty span.  Returns the top row.  One thread.
-__device__ int v1_fill_spans(const short2* v, int n, int W, int H, short2* span, int* rows_out) {
-  const long long XY_ONE = 1 << 16;
-  int xmin = v[0].x, xmax = v[0].x, ymin = v[0].y, ymax = v[0].y, imin = 0;
-  for (int i = 0; i < n; i++) {
-    if (v[i].y < ymin) {
-      ymin = v[i].y;
-      imin = i;
+// icvFetchContour on the pieces: follows the border that starts at (x0, y0), writes the CHAIN_APPROX_SIMPLE
+// vertices and records, for every border pixel whose right neighbour the search examined and found empty, the
+// contour id on that pixel's piece (the "-nbd" mark of the library: only run ends can carry it).  Returns the
+// vertex count, -1 if the pool is exhausted or the walk does not close.  One group; `verts` is lane 0's.
+__device__ int v1_trace(const V1Grid& g, int x0, int y0, bool is_hole, unsigned short cid, V1Verts& verts,
+                        unsigned short* mark, int lane) {
+  const int r = lane & 7;
+  int n = 0, ok = 1;
+  int s_end = is_hole ? 0 : 4;
+  // the library looks clockwise from s_end - 1 for the first set neighbour; reaching s_end again = single pixel
+  int s = (s_end - 1 - r) & 7;
+  unsigned hit = v1_gballot(r < 7 && v1_piece_at(g, x0 + v1_dx(s), y0 + v1_dy(s)) >= 0, lane);
+  int j3 = v1_piece_at(g, x0, y0);   // piece of the current border pixel
+  if (!hit) {
+    if (r == 0) {
+      mark[j3] = cid;
+      ok = verts.push(0, make_short2((short)x0, (short)y0));
     }
-    ymax = ymax > v[i].y ? ymax : v[i].y;
-    xmax = xmax > v[i].x ? xmax : v[i].x;
-    xmin = xmin < v[i].x ? xmin : v[i].x;
+    return __shfl(ok, 0, 8) ? 1 : -1;
   }
-  const int nrows = ymax - ymin + 1;
-  *rows_out = nrows;
-  for (int r = 0; r < nrows; r++) span[r] = make_short2(1, 0);
-  if (n < 3 || xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return ymin;
-  ymax = ymax < H - 1 ? ymax : H - 1;
-  int edges = n;
-  int e_idx[2] = {imin, imin}, e_ye[2] = {ymin, ymin}, e_di[2] = {1, n - 1};
-  long long e_x[2] = {-XY_ONE, -XY_ONE}, e_dx[2] = {0, 0};
-  int y = ymin;
-  do {
-    for (int i = 0; i < 2; i++) {
-      if (y >= e_ye[i]) {
-        int idx0 = e_idx[i];
-        const int di = e_di[i];
-        int idx = idx0 + di;
-        if (idx >= n) idx -= n;
-        for (; edges-- > 0;) {
-          const int ty = v[idx].y;
-          if (ty > y) {
-            const long long xs = (long long)v[idx0].x << 16, xe = (long long)v[idx].x << 16;
-            e_ye[i] = ty;
-            e_dx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));   // C division: towards zero, as the library's
-            e_x[i] = xs;
-            e_idx[i] = idx;
-            break;
-          }
-          idx0 = idx;
-          idx += di;
+  s = (s_end - __ffs(hit)) & 7;
+  const int i1x = x0 + v1_dx(s), i1y = y0 + v1_dy(s);
+  int i3x = x0, i3y = y0, prev_s = s ^ 4;
+  int guard = 0;
+  for (; guard < V1_TRACE_CAP; guard++) {
+    s_end = s;
+    const int sk = (s_end + 1 + r) & 7;   // lane r: the (r+1)-th direction of the counter-clockwise search
+    const int px = i3x + v1_dx(sk), py = i3y + v1_dy(sk);
+    const int jk = v1_piece_at(g, px, py);
+    hit = v1_gballot(jk >= 0, lane);
+    if (!hit) return -1;                  // (cannot happen: the pixel the walk came from is set)
+    const int k0 = __ffs(hit) - 1;
+    s = (s_end + 1 + k0) & 7;
+    const int i4x = __shfl(px, k0, 8), i4y = __shfl(py, k0, 8), j4 = __shfl(jk, k0, 8);
+    if ((unsigned)(s - 1) < (unsigned)s_end && r == 0) mark[j3] = cid;
+    if (s != prev_s) {
+      if (r == 0 && ok) ok = verts.push(n, make_short2((short)i3x, (short)i3y));
+      n++;
+      prev_s = s;
+    }
+    if (i4x == x0 && i4y == y0 && i3x == i1x && i3y == i1y) break;
+    i3x = i4x;
+    i3y = i4y;
+    j3 = j4;
+    s = (s + 4) & 7;
+  }
+  verts.base = __shfl(verts.base, 0, 8);
+  __threadfence_block();   // lane 0's vertices, read by the whole group from here on
+  return (guard < V1_TRACE_CAP && __shfl(ok, 0, 8)) ? n : -1;
+}
+
+// running first-raster maximum of the smoothed map over painted mask pixels (one thread's state)
+struct V1Paint {
+  V1Grid g;
+  const float* bval;            // LDS, per piece: its maximum of the smoothed map
+  const unsigned short* byrow;  // LDS, per piece: its index in R
+  const V1Run* R;
+  const float* plane;
+  int hs, ws;
+  unsigned long long cur;
+};
+
+// pixels [lo, hi] of piece j (row y) are painted
+__device__ void v1_consider(V1Paint& p, int j, int y, int lo, int hi) {
+  if (__float_as_uint(p.bval[j]) < (unsigned)(p.cur >> 32)) return;  // nothing in the piece can win
+  const V1Run r = p.R[p.byrow[j]];
+  if (r.bx >= lo && r.bx <= hi) {
+    const unsigned long long k = v1_key(r.best, r.bx, y, p.g.W);
+    p.cur = k > p.cur ? k : p.cur;
+    return;
+  }
+  for (int x = lo; x <= hi; x++) {
+    const unsigned long long k = v1_key(v1_smooth_at(p.plane, p.hs, p.ws, p.g.W, p.g.H, x, y), x, y, p.g.W);
+    p.cur = k > p.cur ? k : p.cur;
+  }
+}
+
+// columns [x1, x2] of row y are painted: pieces of ANY blob under them count, as in cv2
+__device__ void v1_paint_span(V1Paint& p, int y, int x1, int x2) {
+  if (y < 0 || y >= p.g.H) return;
+  for (int j = p.g.rowoff[y]; j < p.g.rowoff[y + 1]; j++) {
+    const short2 q = p.g.srun[j];
+    if (q.x > x2) break;
+    if (q.y < x1) continue;
+    v1_consider(p, j, y, x1 > q.x ? x1 : q.x, x2 < q.y ? x2 : q.y);
+  }
+}
+
+__device__ __forceinline__ unsigned long long v1_gmax(unsigned long long k) {
+  for (int o = 1; o < 8; o <<= 1) {
+    const unsigned long long t = __shfl_xor(k, o, 8);
+    k = t > k ? t : k;
+  }
+  return k;
+}
+
+// FillConvexPoly (lineType 8, shift 0) of the contour v[0 .. n): the two edge walkers' span in every row from the
+// polygon's top row on, then the outline (the polygon's edges are straight 8-connected pixel chains).  One group:
+// every lane runs the walkers (a few additions per row), lane k paints the k-th row of each 8; outline edges are
+// dealt round-robin.  On return p.cur is the group's maximum in every lane.
+__device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
+  const int W = p.g.W, H = p.g.H, r = lane & 7;
+  const long long XY_ONE = 1 << 16;
+  int xmin = 0x7fffffff, xmax = -0x7fffffff, ymax = -0x7fffffff, ykey = 0x7fffffff;   // ykey = (y << 16) | index
+  for (int i = r; i < n; i += 8) {
+    const short2 q = v[i];
+    const int k = ((int)q.y << 16) | i;
+    ykey = k < ykey ? k : ykey;
+    ymax = ymax > q.y ? ymax : q.y;
+    xmax = xmax > q.x ? xmax : q.x;
+    xmin = xmin < q.x ? xmin : q.x;
+  }
+  for (int o = 1; o < 8; o <<= 1) {
+    const int a = __shfl_xor(ykey, o, 8), b = __shfl_xor(ymax, o, 8), c = __shfl_xor(xmax, o, 8),
+              d = __shfl_xor(xmin, o, 8);
+    ykey = a < ykey ? a : ykey;
+    ymax = b > ymax ? b : ymax;
+    xmax = c > xmax ? c : xmax;
+    xmin = d < xmin ? d : xmin;
+  }
+  const int ymin = ykey >> 16, imin = ykey & 0xffff;   // the first vertex of the top row
+  if (!(n < 3 || xmax < 0 || ymax < 0 || xmin >= W || ymin >= H)) {
+    ymax = ymax < H - 1 ? ymax : H - 1;
+    int edges = n;
+    int e_idx[2] = {imin, imin}, e_ye[2] = {ymin, ymin}, e_di[2] = {1, n - 1};
+    long long e_x[2] = {-XY_ONE, -XY_ONE}, e_dx[2] = {0, 0};
+    int y = ymin, cnt = 0, my_y = -1, my_x1 = 1, my_x2 = 0;
+    do {
+      for (int i = 0; i < 2; i++) {
+        if (y >= e_ye[i]) {
+          int idx0 = e_idx[i];
+          const int di = e_di[i];
+          int idx = idx0 + di;
           if (idx >= n) idx -= n;
+          for (; edges-- > 0;) {
+            const int ty = v[idx].y;
+            if (ty > y) {
+              const long long xs = (long long)v[idx0].x << 16, xe = (long long)v[idx].x << 16;
+              e_ye[i] = ty;
+              e_dx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));   // C division: towards zero, as the library's
+              e_x[i] = xs;
+              e_idx[i] = idx;
+              break;
+            }
+            idx0 = idx;
+            idx += di;
+            if (idx >= n) idx -= n;
+          }
+        }
+      }
+      if (edges < 0) break;
+      if (y >= 0) {
+        const int left = e_x[0] > e_x[1] ? 1 : 0, right = 1 - left;
+        int xx1 = (int)((e_x[left] + (XY_ONE >> 1)) >> 16), xx2 = (int)((e_x[right] + (XY_ONE >> 1)) >> 16);
+        if (xx2 >= 0 && xx1 < W && (cnt & 7) == r) {
+          my_y = y;
+          my_x1 = xx1 < 0 ? 0 : xx1;
+          my_x2 = xx2 >= W ? W - 1 : xx2;
+        }
+        if ((++cnt & 7) == 0) {
+          if (my_y >= 0) v1_paint_span(p, my_y, my_x1, my_x2);
+          my_y = -1;
+        }
+      }
+      e_x[0] += e_dx[0];
+      e_x[1] += e_dx[1];
+    } while (++y <= ymax);
+    if (my_y >= 0) v1_paint_span(p, my_y, my_x1, my_x2);
+    p.cur = v1_gmax(p.cur);   // the outline's skip test starts from the whole fill's maximum
+  }
+  // outline
+  if (n == 1) {
+    if (r == 0) v1_paint_span(p, v[0].y, v[0].x, v[0].x);
+  } else {
+    int cj = -1, cy = -1;  // piece of the previous outline pixel
+    for (int e = r; e < n; e += 8) {
+      const short2 a = v[e == 0 ? n - 1 : e - 1], c = v[e];
+      const int dx = c.x - a.x, dy = c.y - a.y;
+      if (dy == 0) {
+        v1_paint_span(p, a.y, dx > 0 ? a.x : c.x, dx > 0 ? c.x : a.x);
+      } else {
+        const int steps = abs(dy);  // vertical or diagonal chain
+        const int sx = (dx > 0) - (dx < 0), sy = dy > 0 ? 1 : -1;
+        for (int t = 1; t <= steps; t++) {
+          const int x = a.x + t * sx, y = a.y + t * sy;
+          if (!(cj >= 0 && y == cy && p.g.srun[cj].x <= x && x <= p.g.srun[cj].y)) {
+            cj = v1_piece_at(p.g, x, y);
+            cy = y;
+          }
+          if (cj >= 0) v1_consider(p, cj, y, x, x);
         }
       }
     }
-    if (edges < 0) break;
-    if (y >= 0) {
-      const int left = e_x[0] > e_x[1] ? 1 : 0, right = 1 - left;
-      int xx1 = (int)((e_x[left] + (XY_ONE >> 1)) >> 16), xx2 = (int)((e_x[right] + (XY_ONE >> 1)) >> 16);
-      if (xx2 >= 0 && xx1 < W) {
-        xx1 = xx1 < 0 ? 0 : xx1;
-        xx2 = xx2 >= W ? W - 1 : xx2;
-        span[y - ymin] = make_short2((short)xx1, (short)xx2);
-      }
-    }
-    e_x[0] += e_dx[0];
-    e_x[1] += e_dx[1];
-  } while (++y <= ymax);
-  return ymin;
+  }
+  p.cur = v1_gmax(p.cur);
 }
 
 // ---------------------------------------------------------------------------
@@ -449,13 +577,13 @@ __device__ void uf_union(int* parent, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
-                                                       int W, int H, int n_parts, int run_cap, int kp_cap,
-                                                       const int* __restrict__ n_runs,
-                                                       const V1Run* __restrict__ runs,
+__global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__ net_out, int C, int hs, int ws, int W,
+                                                       int H, int n_parts, int run_cap, int kp_cap, int vert_cap,
+                                                       const int* __restrict__ n_runs, const V1Run* __restrict__ runs,
                                                        unsigned long long* __restrict__ ws_best,
-                                                       int* __restrict__ ws_first, float* __restrict__ kps,
-                                                       int* __restrict__ n_kps, int* __restrict__ overflow) {
+                                                       int* __restrict__ ws_first, short2* __restrict__ ws_verts,
+                                                       float* __restrict__ kps, int* __restrict__ n_kps,
+                                                       int* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) int ismem[];
   const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   int n = n_runs[(size_t)b * n_parts + part];
@@ -469,25 +597,44 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   const V1Run* R = runs + ((size_t)b * n_parts + part) * run_cap;
   unsigned long long* best = ws_best + ((size_t)b * n_parts + part) * run_cap;
   int* first = ws_first + ((size_t)b * n_parts + part) * run_cap * 3;
-  int* parent = ismem;              // n
-  int* byrow = parent + run_cap;    // n: run indices grouped by row
-  int* rowoff = byrow + run_cap;    // H + 2
-  int* roots = rowoff + H + 2;      // kp_cap
-  __shared__ int s_nroot;
+  short2* vpool = ws_verts + ((size_t)b * n_parts + part) * vert_cap;
+  // LDS: the mask as pieces sorted by (row, xs); every table below is indexed by sorted position
+  int* parent = ismem;                                          // run_cap: union-find, then each piece's blob root
+  int* rowoff = parent + run_cap;                               // H + 2
+  int* roots = rowoff + H + 2;                                  // kp_cap: the blobs' root pieces
+  float* bval = (float*)(roots + kp_cap);                       // run_cap: the piece's maximum
+  short2* srun = (short2*)(bval + run_cap);                     // run_cap: {xs, xe}
+  unsigned short* byrow = (unsigned short*)(srun + run_cap);    // run_cap: index in R
+  unsigned short* mark = byrow + run_cap;                       // run_cap: contour id + 1 of the trace that last
+                                                                //          right-marked the piece's last pixel
+  auto up = [](void* p_, size_t a) { return (char*)(((size_t)p_ + a - 1) & ~(a - 1)); };
+  unsigned long long* c_key = (unsigned long long*)up(mark + run_cap, 8);  // per contour: arg-max key
+  int* c_disc = (int*)(c_key + kp_cap);          // discovery position (raster index of the border's start)
+  short* c_par = (short*)(c_disc + kp_cap);      // parent contour, -1 = the frame
+  short* c_link = c_par + kp_cap;                // outer borders: the border met last before their first pixel
+  short* c_depth = c_link + kp_cap;
+  unsigned short* irr = (unsigned short*)(c_depth + kp_cap);   // blobs that need the literal walk
+  unsigned char* c_hole = (unsigned char*)(irr + kp_cap);
+  __shared__ int s_nroot, s_nirr, s_ncont, s_vused;
   __shared__ int s_scan[256];
 
   for (int i = tid; i < H + 2; i += 256) rowoff[i] = 0;
-  if (tid == 0) s_nroot = 0;
+  if (tid == 0) {
+    s_nroot = 0;
+    s_nirr = 0;
+    s_vused = 0;
+  }
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
     parent[i] = i;
+    mark[i] = 0;
     atomicAdd(&rowoff[R[i].y + 1], 1);
     best[i] = 0ull;
     first[i] = 0x7fffffff;
     first[run_cap + i] = -1;      // last row of the blob rooted here
     first[2 * run_cap + i] = 0;   // its number of runs
   }
-  __threadfence();  // the initial values must be in L2 before any atomic of step 3 lands there
+  __threadfence();  // the initial values must be in L2 before any atomic of the statistics step lands there
   __syncthreads();
   // exclusive scan of the per-row counts (rowoff[y+1] = count of row y)
   {
@@ -514,42 +661,67 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  // rowoff[y+1] now = start of row y; scatter with a moving cursor, then restore
-  for (int i = tid; i < n; i += 256) byrow[atomicAdd(&rowoff[R[i].y + 1], 1)] = i;
-  __syncthreads();
-  // after the scatter rowoff[y+1] = end of row y = start of row y+1; row y spans [rowoff[y], rowoff[y+1])
-  // with rowoff[0] = 0 (row -1 is empty)
+  // rowoff[y+1] now = start of row y; scatter with a moving cursor: afterwards rowoff[y+1] = end of row y = start
+  // of row y+1, so row y spans [rowoff[y], rowoff[y+1]) with rowoff[0] = 0 (row -1 is empty)
   for (int i = tid; i < n; i += 256) {
     const V1Run r = R[i];
-    // same row: tile seams (xs == neighbour's xe + 1); previous row: 8-connectivity
-    for (int j = rowoff[r.y]; j < rowoff[r.y + 1]; j++) {
-      const int o = byrow[j];
-      if (o != i && R[o].xe + 1 == r.xs) uf_union(parent, i, o);
-    }
-    if (r.y > 0)
-      for (int j = rowoff[r.y - 1]; j < rowoff[r.y]; j++) {
-        const int o = byrow[j];
-        const V1Run q = R[o];
-        if (q.xs <= r.xe + 1 && q.xe >= r.xs - 1) uf_union(parent, i, o);
+    const int pos = atomicAdd(&rowoff[r.y + 1], 1);
+    byrow[pos] = (unsigned short)i;
+    srun[pos] = make_short2((short)r.xs, (short)r.xe);
+    bval[pos] = r.best;
+  }
+  __syncthreads();
+  for (int y = tid; y < H; y += 256) {   // order each row by xs (a handful of pieces: insertion sort)
+    const int lo = rowoff[y], hi = rowoff[y + 1];
+    for (int a = lo + 1; a < hi; a++) {
+      const short2 sv = srun[a];
+      const unsigned short bv = byrow[a];
+      const float fv = bval[a];
+      int q = a - 1;
+      while (q >= lo && srun[q].x > sv.x) {
+        srun[q + 1] = srun[q];
+        byrow[q + 1] = byrow[q];
+        bval[q + 1] = bval[q];
+        q--;
       }
+      srun[q + 1] = sv;
+      byrow[q + 1] = bv;
+      bval[q + 1] = fv;
+    }
+  }
+  __syncthreads();
+  // union pieces that touch: same row across a tile seam (xs == left neighbour's xe + 1); previous row: 8-connectivity
+  for (int j = tid; j < n; j += 256) {
+    const int y = R[byrow[j]].y;
+    const short2 r = srun[j];
+    if (j > rowoff[y] && srun[j - 1].y + 1 == r.x) uf_union(parent, j, j - 1);
+    if (y > 0)
+      for (int k = rowoff[y - 1]; k < rowoff[y]; k++) {
+        const short2 q = srun[k];
+        if (q.x > r.y + 1) break;
+        if (q.y >= r.x - 1) uf_union(parent, j, k);
+      }
+  }
+  __syncthreads();
+  for (int j = tid; j < n; j += 256) {   // full path compression: parent[j] = the blob's root from here on
+    const int root = uf_find(parent, j);
+    parent[j] = root;                    // (concurrent finds read either an ancestor or the root: both lead there)
   }
   __syncthreads();
   // per-blob first-raster maximum, first pixel, last row and number of (seam-merged) runs
   int* ymaxv = first + run_cap;
   int* nrunv = first + 2 * run_cap;
-  for (int i = tid; i < n; i += 256) {
-    const int root = uf_find(parent, i);
-    const V1Run r = R[i];
+  for (int j = tid; j < n; j += 256) {
+    const int root = parent[j];
+    const V1Run r = R[byrow[j]];
     const unsigned pos = (unsigned)(r.y * W + r.bx);
     atomicMax(&best[root], ((unsigned long long)__float_as_uint(r.best) << 32) | (0xffffffffu - pos));
     atomicMin(&first[root], r.y * W + r.xs);
     atomicMax(&ymaxv[root], r.y);
-    bool cont = false;  // continues a run cut at a tile seam
-    for (int j = rowoff[r.y]; j < rowoff[r.y + 1]; j++) cont |= R[byrow[j]].xe + 1 == r.xs;
-    if (!cont) atomicAdd(&nrunv[root], 1);
-    if (root == i) {
+    if (!(j > rowoff[r.y] && srun[j - 1].y + 1 == r.xs)) atomicAdd(&nrunv[root], 1);
+    if (root == j) {
       const int s = atomicAdd(&s_nroot, 1);
-      if (s < kp_cap) roots[s] = i; else *overflow = 1;
+      if (s < kp_cap) roots[s] = j; else *overflow = 1;
     }
   }
   __threadfence_block();
@@ -557,240 +729,154 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   const int nr = s_nroot < kp_cap ? s_nroot : kp_cap;
   auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
-  // blobs with more than one run in some row need the literal contour + fill (see the helpers' header)
-  __shared__ int s_nirr;
-  if (tid == 0) s_nirr = 0;
-  __syncthreads();
+  // the contour table starts with the blobs' outer borders; blobs with more than one run in some row need the
+  // literal contour + fill (see the helpers' header), every other blob's keypoint is its component's arg-max
+  if (tid == 0) s_ncont = nr;
   for (int i = tid; i < nr; i += 256) {
     const int me = roots[i];
-    if (ld(&nrunv[me]) != ld(&ymaxv[me]) - ld(&first[me]) / W + 1) atomicAdd(&s_nirr, 1);
+    const int fp = ld(&first[me]);
+    c_disc[i] = fp;
+    c_par[i] = -1;
+    c_link[i] = -1;
+    c_hole[i] = 0;
+    c_key[i] = __hip_atomic_load(&best[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ld(&nrunv[me]) != ld(&ymaxv[me]) - fp / W + 1) irr[atomicAdd(&s_nirr, 1)] = (unsigned short)i;
   }
   __syncthreads();
-  if (s_nirr == 0) {
-    // findContours list order: reverse raster order of each blob's first pixel
-    for (int i = tid; i < nr; i += 256) {
-      const int me = roots[i];
-      const int fp = ld(&first[me]);
-      int rank = 0;
-      for (int j = 0; j < nr; j++) rank += ld(&first[roots[j]]) > fp;
-      const unsigned long long k = __hip_atomic_load(&best[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned pos = 0xffffffffu - (unsigned)(k & 0xffffffffu);
-      const int y = pos / W, x = pos - y * W;
-      out[rank * 3 + 0] = (float)x;
-      out[rank * 3 + 1] = (float)y;
-      out[rank * 3 + 2] = resize_at(plane, hs, ws, W, H, x, y);
-    }
-    if (tid == 0) *out_n = nr;
-    return;
-  }
-
-  // ---- literal path ------------------------------------------------------------------------------------------
-  auto up = [](void* p_, size_t a) { return (char*)(((size_t)p_ + a - 1) & ~(a - 1)); };
-  unsigned long long* c_key = (unsigned long long*)up(roots + kp_cap, 8);  // arg-max key per contour
-  int* c_disc = (int*)(c_key + kp_cap);          // discovery position (raster index of the border's start)
-  short* c_par = (short*)(c_disc + kp_cap);      // parent contour, -1 = the frame
-  short* c_ord = c_par + kp_cap;                 // output order
-  unsigned char* c_hole = (unsigned char*)(c_ord + kp_cap);
-  unsigned short* mark = (unsigned short*)up(c_hole + kp_cap, 2);   // per run: contour id + 1 of the trace that
-  short2* verts = (short2*)up(mark + run_cap, 4);                   // right-marked its last pixel
-  short2* span = verts + V1_VCAP;                                   // H
-  __shared__ unsigned long long s_key;
-  __shared__ int s_nv, s_top, s_rows, s_ncont, s_go, s_hx, s_hy;
-  const V1Rows g = {R, byrow, rowoff, W, H};
-  for (int i = tid; i < n; i += 256) mark[i] = 0;
-  if (tid == 0) s_ncont = nr;
-  __syncthreads();
-  // maximum of the smoothed map over what fillConvexPoly paints for the contour in verts[0 .. s_nv)
-  auto paint_max = [&]() {
-    const int nv = s_nv, top = s_top, nrows = s_rows;
-    for (int e = tid; e < nv; e += 256) {          // outline: the polygon's edges are straight 8-connected runs
-      const short2 a = verts[e == 0 ? nv - 1 : e - 1], c = verts[e];
-      const int dx = c.x - a.x, dy = c.y - a.y;
-      const int steps = abs(dx) > abs(dy) ? abs(dx) : abs(dy);
-      const int sx = (dx > 0) - (dx < 0), sy = (dy > 0) - (dy < 0);
-      for (int t = 0; t <= steps; t++) {
-        const int x = a.x + t * sx, y = a.y + t * sy;
-        atomicMax(&s_key, v1_key(v1_smooth_at(plane, hs, ws, W, H, x, y), x, y, W));
-      }
-    }
-    for (int r = tid; r < nrows; r += 256) {       // scan fill: runs of ANY blob under the span count, as in cv2
-      const short2 sp = span[r];
-      if (sp.x > sp.y) continue;
-      const int y = top + r;
-      if (y < 0 || y >= H) continue;
-      for (int j = rowoff[y]; j < rowoff[y + 1]; j++) {
-        const V1Run q = R[byrow[j]];
-        const int lo = sp.x > q.xs ? sp.x : q.xs, hi = sp.y < q.xe ? sp.y : q.xe;
-        if (lo > hi) continue;
-        if (lo == q.xs && hi == q.xe) {
-          atomicMax(&s_key, v1_key(q.best, q.bx, y, W));
-        } else {
-          for (int x = lo; x <= hi; x++) atomicMax(&s_key, v1_key(v1_smooth_at(plane, hs, ws, W, H, x, y), x, y, W));
-        }
-      }
-    }
-  };
-  for (int i = 0; i < nr; i++) {                   // (block-uniform loop)
-    const int me = roots[i];
-    const int fp = ld(&first[me]), y_last = ld(&ymaxv[me]);
-    const bool simple = ld(&nrunv[me]) == y_last - fp / W + 1;
-    if (tid == 0) {
-      c_disc[i] = fp;
-      c_par[i] = -1;
-      c_hole[i] = 0;
-      if (simple) c_key[i] = __hip_atomic_load(&best[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (simple) continue;
-    // outer border: starts at the blob's first raster pixel
-    if (tid == 0) {
-      s_key = 0ull;
-      s_nv = v1_trace(g, fp % W, fp / W, false, (unsigned short)(i + 1), verts, mark);
-      if (s_nv < 0) {
-        *overflow = 1;
-        s_nv = 0;
-        s_rows = 0;
-      } else {
-        int nrows;
-        s_top = v1_fill_spans(verts, s_nv, W, H, span, &nrows);
-        s_rows = nrows;
-      }
-    }
-    __syncthreads();
-    paint_max();
-    __syncthreads();
-    if (tid == 0) c_key[i] = s_key;
-    // hole borders: the blob's run ends, in raster order, that no trace so far has right-marked
-    int cy = fp / W, cx = -1;
-    for (;;) {
-      if (tid == 0) {
-        s_go = 0;
-        for (int y = cy; y <= y_last && !s_go; y++) {
-          int bestx = 0x7fffffff, bestrun = -1;
-          for (int j = rowoff[y]; j < rowoff[y + 1]; j++) {
-            const int o = byrow[j];
-            const int xe = R[o].xe;
-            if ((y == cy && xe <= cx) || xe >= bestx || mark[o] != 0 || uf_find(parent, o) != me) continue;
-            bool cont = false;  // cut at a tile seam: the run goes on, this is not its end
-            for (int j2 = rowoff[y]; j2 < rowoff[y + 1]; j2++) cont |= R[byrow[j2]].xs == xe + 1;
-            if (cont) continue;
-            bestx = xe;
-            bestrun = o;
-          }
-          if (bestrun >= 0) {
-            s_go = 1;
-            s_hx = bestx;
-            s_hy = y;
-          }
-        }
-        if (s_go) {
-          const int c = s_ncont;
-          if (c >= kp_cap) {
-            *overflow = 1;
-            s_go = 0;
-          } else {
-            s_ncont = c + 1;
-            c_disc[c] = s_hy * W + s_hx;         // (discovered one pixel further right; same order among holes)
-            c_par[c] = (short)i;
-            c_hole[c] = 1;
-            s_key = 0ull;
-            s_nv = v1_trace(g, s_hx, s_hy, true, (unsigned short)(c + 1), verts, mark);
-            if (s_nv < 0) {
-              *overflow = 1;
-              s_nv = 0;
-              s_rows = 0;
-            } else {
-              int nrows;
-              s_top = v1_fill_spans(verts, s_nv, W, H, span, &nrows);
-              s_rows = nrows;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if (!s_go) break;
-      paint_max();
-      __syncthreads();
-      if (tid == 0) c_key[s_ncont - 1] = s_key;
-      cy = s_hy;
-      cx = s_hx;
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-  const int nc = s_ncont;
-  if (tid == 0) {
-    // parents of the outer borders (RETR_TREE): the border met last on the first pixel's row = the one that
-    // right-marked the nearest run end to its left; a hole border is the parent itself, an outer border hands
-    // on its own parent.  Resolved in discovery order (a parent is always discovered first).
-    if (nc > nr) {
-      for (int k = 0; k < nr; k++) c_ord[k] = (short)k;
-      for (int a = 1; a < nr; a++) {               // insertion sort by discovery position
-        const short v = c_ord[a];
-        int q = a - 1;
-        while (q >= 0 && c_disc[c_ord[q]] > c_disc[v]) {
-          c_ord[q + 1] = c_ord[q];
-          q--;
-        }
-        c_ord[q + 1] = v;
-      }
-      for (int k = 0; k < nr; k++) {
-        const int X = c_ord[k];
-        const int x0 = c_disc[X] % W, y0 = c_disc[X] / W;
-        int bx = -1, brun = -1;
-        for (int j = rowoff[y0]; j < rowoff[y0 + 1]; j++) {
-          const int o = byrow[j];
-          if (R[o].xe < x0 && R[o].xe > bx) {
-            bx = R[o].xe;
-            brun = o;
-          }
-        }
-        int par = -1;
-        if (brun >= 0) {
-          int Bp = (int)mark[brun] - 1;
-          if (Bp < 0) {                            // a simple blob: its only border is its outer one
-            const int rt = uf_find(parent, brun);
-            for (int q = 0; q < nr; q++)
-              if (roots[q] == rt) Bp = q;
-          }
-          par = c_hole[Bp] ? Bp : c_par[Bp];
-        }
-        c_par[X] = (short)par;
-      }
-    }
-    // list order of cvTreeToNodeSeq: a node, its children, its next sibling; siblings latest-discovered first
-    int emitted = 0, sp_ = 0;
-    short* stack = (short*)span;                    // (the span table is free now)
-    auto push_children = [&](int node) {
-      // ascending discovery onto the stack, so the latest is popped first
-      int last = -1;
+  const int nirr = s_nirr;
+  if (nirr) {
+    const V1Grid g = {srun, rowoff, W, H};
+    V1Paint pt = {g, bval, byrow, R, plane, hs, ws, 0ull};
+    // blob k of the list -> thread (k % 4) * 64 + k / 4: spread over the four waves first
+    V1Verts vv = {vpool, &s_vused, vert_cap, 0, 0};
+    const int lane = tid & 63, r = tid & 7;
+    for (int k = tid >> 3; k < nirr; k += 32) {   // one group of 8 lanes per blob
+      const int i = irr[k], me = roots[i];
+      const int fp = c_disc[i], y_first = fp / W, y_last = ld(&ymaxv[me]);
+      int c = i, sx = fp - y_first * W, sy = y_first;   // the outer border starts at the blob's first raster pixel
+      bool hole = false;
       for (;;) {
-        int pick = -1;
-        for (int c = 0; c < nc; c++)
-          if (c_par[c] == node && c_disc[c] > last && (pick < 0 || c_disc[c] < c_disc[pick])) pick = c;
-        if (pick < 0) break;
-        stack[sp_++] = (short)pick;
-        last = c_disc[pick];
+        const int nv = v1_trace(g, sx, sy, hole, (unsigned short)(c + 1), vv, mark, lane);
+        if (nv <= 0) {
+          *overflow = 1;
+          break;
+        }
+        pt.cur = 0ull;
+        v1_fill_paint(pt, vpool + vv.base, nv, lane);
+        if (r == 0) c_key[c] = pt.cur;
+        // next hole border: the blob's first run end in raster order, from here on, that no trace has right-marked
+        // (lane k looks at the k-th row of each 8)
+        int hx = -1, hy = -1;
+        for (int yb = sy; yb <= y_last && hx < 0; yb += 8) {
+          const int y = yb + r;
+          int fx = -1;
+          if (y <= y_last)
+            for (int j = rowoff[y]; j < rowoff[y + 1]; j++) {
+              const short2 q = srun[j];
+              if ((hole && y == sy && q.y <= sx) || mark[j] != 0 || parent[j] != me) continue;
+              if (j + 1 < rowoff[y + 1] && srun[j + 1].x == q.y + 1) continue;   // cut at a tile seam: not the run's end
+              fx = q.y;
+              break;
+            }
+          const unsigned hit = v1_gballot(fx >= 0, lane);
+          if (hit) {
+            const int k0 = __ffs(hit) - 1;
+            hx = __shfl(fx, k0, 8);
+            hy = yb + k0;
+          }
+        }
+        if (hx < 0) break;
+        if (r == 0) c = atomicAdd(&s_ncont, 1);
+        c = __shfl(c, 0, 8);
+        if (c >= kp_cap) {
+          *overflow = 1;
+          break;
+        }
+        if (r == 0) {
+          c_disc[c] = hy * W + hx;   // (discovered one pixel further right; same order among holes)
+          c_par[c] = (short)i;
+          c_link[c] = -1;
+          c_hole[c] = 1;
+          c_key[c] = 0ull;
+        }
+        sx = hx;
+        sy = hy;
+        hole = true;
       }
-    };
-    push_children(-1);
-    while (sp_ > 0) {
-      const int c = stack[--sp_];
-      c_ord[emitted++] = (short)c;
-      push_children(c);
     }
-    s_ncont = emitted;
+    __syncthreads();
   }
-  __syncthreads();
-  const int total = s_ncont;
-  for (int k = tid; k < total; k += 256) {
-    const unsigned long long key = c_key[c_ord[k]];
-    const unsigned pos = 0xffffffffu - (unsigned)(key & 0xffffffffu);
+  const int nc = s_ncont < kp_cap ? s_ncont : kp_cap;
+  if (nc > nr) {
+    // parents of the outer borders (RETR_TREE): the border met last on the first pixel's row = the one that
+    // right-marked the nearest run end to its left; a hole border is the parent itself, an outer border hands on
+    // its own parent (its first pixel comes earlier in raster order, so the chain ends)
+    for (int X = tid; X < nr; X += 256) {
+      const int fp = c_disc[X], y0 = fp / W, x0 = fp - y0 * W;
+      const int j0 = v1_piece_at({srun, rowoff, W, H}, x0, y0);
+      int link = -1;
+      if (j0 > rowoff[y0]) {
+        link = (int)mark[j0 - 1] - 1;
+        if (link < 0) {   // a simple blob: its only border is its outer one
+          const int rt = parent[j0 - 1];
+          for (int q = 0; q < nr; q++)
+            if (roots[q] == rt) link = q;
+        }
+      }
+      c_link[X] = (short)link;
+    }
+    __syncthreads();
+    for (int X = tid; X < nr; X += 256) {
+      int p = c_link[X];
+      while (p >= 0 && !c_hole[p]) p = c_link[p];
+      c_par[X] = (short)p;
+    }
+    __syncthreads();
+    for (int X = tid; X < nc; X += 256) {
+      int d = 0;
+      for (int p = c_par[X]; p >= 0; p = c_par[p]) d++;
+      c_depth[X] = (short)d;
+    }
+    __syncthreads();
+  }
+  // list order of cvTreeToNodeSeq: a node, its children, its next sibling; siblings latest-discovered first.  A
+  // contour's place = the number of contours that come before it.
+  for (int a = tid; a < nc; a += 256) {
+    int rank = 0;
+    if (nc == nr) {
+      const int da = c_disc[a];
+      for (int q = 0; q < nc; q++) rank += c_disc[q] > da;
+    } else {
+      for (int q = 0; q < nc; q++) {
+        if (q == a) continue;
+        int x = a, y = q, dx = c_depth[a], dy = c_depth[q];
+        while (dx > dy) {
+          x = c_par[x];
+          dx--;
+        }
+        while (dy > dx) {
+          y = c_par[y];
+          dy--;
+        }
+        if (x == y) {   // one is the other's ancestor: the ancestor comes first
+          rank += c_depth[q] < c_depth[a];
+          continue;
+        }
+        while (c_par[x] != c_par[y]) {
+          x = c_par[x];
+          y = c_par[y];
+        }
+        rank += c_disc[y] > c_disc[x];
+      }
+    }
+    const unsigned long long key = c_key[a];
+    const unsigned pos = key ? 0xffffffffu - (unsigned)(key & 0xffffffffu) : 0u;   // (key 0: a walk that overflowed)
     const int y = pos / W, x = pos - y * W;
-    out[k * 3 + 0] = (float)x;
-    out[k * 3 + 1] = (float)y;
-    out[k * 3 + 2] = resize_at(plane, hs, ws, W, H, x, y);
+    out[rank * 3 + 0] = (float)x;
+    out[rank * 3 + 1] = (float)y;
+    out[rank * 3 + 2] = resize_at(plane, hs, ws, W, H, x, y);
   }
-  if (tid == 0) *out_n = total;
+  if (tid == 0) *out_n = nc;
 }
 
 // ---------------------------------------------------------------------------
@@ -960,6 +1046,7 @@ int ph_v1_sizes(const V1Model& m, int B, int W, int H, const V1Caps& c, V1Sizes*
   s->runs = (size_t)B * m.n_parts * c.run_cap * sizeof(V1Run);
   s->ws_best = (size_t)B * m.n_parts * c.run_cap * sizeof(unsigned long long);
   s->ws_first = (size_t)B * m.n_parts * c.run_cap * 3 * sizeof(int);   // first pixel, last row, run count
+  s->ws_verts = (size_t)B * m.n_parts * V1_VERT_POOL(c.run_cap) * sizeof(short2);   // contour vertices
   s->kps = (size_t)B * m.n_parts * c.kp_cap * 3 * sizeof(float);
   s->n_kps = (size_t)B * m.n_parts * sizeof(int);
   s->pairs = (size_t)B * m.n_limbs * c.kp_cap * 3 * sizeof(double);
@@ -980,15 +1067,19 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
       ph_set_error("decode_v1: limb table entry %d out of range", k);
       return -1;
     }
+  if (c.run_cap > 65535 || c.kp_cap > 32767) {
+    ph_set_error("decode_v1: capacities beyond the 16-bit tables (%d runs, %d blobs)", c.run_cap, c.kp_cap);
+    return -1;
+  }
   if (W < 2 || H < 2 || W > 8192 || H > 8192 || (long long)W * H >= 0x7fffffffLL) {
     ph_set_error("decode_v1: bad image size %dx%d", W, H);
     return -1;
   }
   const size_t ldsA = ((size_t)hs * ws + (size_t)(V1_TILE_H + 2) * (V1_TILE_W + 2) +
                        (size_t)(V1_TILE_H + 2) * V1_TILE_W + (size_t)V1_TILE_H * V1_TILE_W) * 4;
-  // K-B: union-find tables + (literal path) contour table, run marks, vertex list, span table
-  const size_t ldsB = ((size_t)2 * c.run_cap + H + 2 + c.kp_cap) * 4 + 8 + (size_t)c.kp_cap * (8 + 4 + 2 + 2 + 1) + 8 +
-                      (size_t)c.run_cap * 2 + (size_t)V1_VCAP * 4 + (size_t)H * 4 + 16;
+  // K-B: the sorted pieces (root, maximum, extents, run index, mark), row offsets, blob and contour tables
+  const size_t ldsB = (size_t)c.run_cap * (4 + 4 + 4 + 2 + 2) + ((size_t)H + 2 + c.kp_cap) * 4 + 8 +
+                      (size_t)c.kp_cap * (8 + 4 + 2 + 2 + 2 + 2 + 1) + 16;
   const size_t ldsC = (size_t)2 * hs * ws * 4;
   const size_t ldsD = (size_t)c.person_cap * (m.n_parts + 1) * 8;
   const size_t lim = 160 * 1024 - 8192;  // static __shared__ tables sit beside the dynamic region
@@ -1013,8 +1104,8 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
                      m.n_parts, c.run_cap, w.n_runs, w.runs, w.overflow);
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(v1_blobs_kernel, dim3(m.n_parts, B), dim3(256), ldsB, stream, net_out, C, hs, ws, W, H, m.n_parts,
-                     c.run_cap, c.kp_cap, (const int*)w.n_runs, (const V1Run*)w.runs, w.ws_best, w.ws_first, w.kps,
-                     w.n_kps, w.overflow);
+                     c.run_cap, c.kp_cap, V1_VERT_POOL(c.run_cap), (const int*)w.n_runs, (const V1Run*)w.runs, w.ws_best,
+                     w.ws_first, w.ws_verts, w.kps, w.n_kps, w.overflow);
   if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
   hipLaunchKernelGGL(v1_pairs_kernel, dim3(m.n_limbs, B), dim3(256), ldsC, stream, net_out, C, hs, ws, W, H, m,
                      c.kp_cap, (const float*)w.kps, (const int*)w.n_kps, w.pairs, w.n_pairs);
