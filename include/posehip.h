@@ -243,14 +243,16 @@ int ph_decode_v2_times(ph_ctx* ctx, float* ms3);
  *      opencv/skeleton.py:102-154, opencv/utils.py:9-173) ----------------------
  * Decodes the ctx's net output for B frames at ORIGINAL-IMAGE resolution
  * W0 x H0 (bilinear-resized maps never materialised).  Host outputs:
- *   n_kps     int32 [B][n_parts]                 keypoints per part (findContours order)
+ *   n_kps     int32 [B][n_parts]                 keypoints per part = contours of findContours(RETR_TREE),
+ *                                                outer AND hole borders, in its list order; each keypoint =
+ *                                                first maximum of the smoothed map under fillConvexPoly(contour)
  *   kps       f32   [B][n_parts][kp_cap][3]      (x, y, score); ids run over parts in order
  *   n_pairs   int32 [B][n_limbs]                 rows per limb, -1 = "invalid pair"
  *   pairs     f64   [B][n_limbs][kp_cap][3]      (idA, idB, mean PAF score)
  *   n_persons int32 [B]
  *   persons   f64   [B][person_cap][n_parts+1]   keypoint ids (-1 = missing) + total score
- * Returns -2 when a capacity (kp_cap blobs per part, person_cap people, 8192
- * mask runs per part) is exceeded. */
+ * Returns -2 when a capacity (kp_cap contours per part, person_cap people, 8192
+ * mask runs or 65536 pooled contour vertices per part) is exceeded. */
 int ph_decode_v1(ph_ctx* ctx, const ph_v1_model* model, int B, int W0, int H0, float conf_thres, int kp_cap,
                  int person_cap, int32_t* n_kps, float* kps, int32_t* n_pairs, double* pairs, int32_t* n_persons,
                  double* persons);

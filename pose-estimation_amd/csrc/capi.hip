@@ -1224,7 +1224,7 @@ int ph_decode_v1(ph_ctx* c, const ph_v1_model* m, int B, int W0, int H0, float c
   PH_CHECK(hipMemcpyAsync(&overflow, c->v1.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
   PH_CHECK(hipStreamSynchronize(s));
   if (overflow) {
-    ph_set_error("ph_decode_v1: capacity exceeded (more than %d mask runs or %d blobs per part, or %d people)",
+    ph_set_error("ph_decode_v1: capacity exceeded (more than %d mask runs or %d contours per part, the contour vertex pool, or %d people)",
                  caps.run_cap, kp_cap, person_cap);
     return -2;
   }
