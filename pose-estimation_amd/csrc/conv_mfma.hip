@@ -853,16 +853,16 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     const int m = Qc0 + tid;
     const int hw = p.H * p.W;
     const int mc = m < p.M ? m : p.M - 1;
-    const int b = mc / hw;
+    const int b = p.magic_e1 ? (int)__umulhi((unsigned)mc, p.magic_e1) : mc / hw;
     const int rem = mc - b * hw;
-    const int y = rem / p.W;
+    const int y = p.magic_e1 ? (int)__umulhi((unsigned)rem, p.magic_e2) : rem / p.W;
     s_row[tid] = make_int2(m < p.M ? b : -1, (y << 16) | (rem - y * p.W));
   } else if (p.halo_mode == 0) {  // output row tid is padded-linear pixel Qc0 + tid: border pixels are dropped
     const int Qc = Qc0 + tid;
     const int HWp = Hp * Wp;
-    const int b = Qc / HWp;
+    const int b = p.magic_e1 ? (int)__umulhi((unsigned)Qc, p.magic_e1) : Qc / HWp;
     const int rem = Qc - b * HWp;
-    const int yp = rem / Wp;
+    const int yp = p.magic_e1 ? (int)__umulhi((unsigned)rem, p.magic_e2) : rem / Wp;
     const int xp = rem - yp * Wp;
     const bool ok = b < p.B && yp >= pi && yp < p.H + pi && xp >= pi && xp < p.W + pi;
     s_row[tid] = make_int2(ok ? b : -1, ((yp - pi) << 16) | ((xp - pi) & 0xffff));
@@ -1015,8 +1015,18 @@ static bool no_lin_env() {  // POSEHIP_NO_LIN=1: A/B switch, the generic K loop 
   return e && e[0] == '1';
 }
 
+// The epilogue's row table splits a pixel index < n_max by d1 (pixels per image), the rest by d2 (pixels per row):
+// multiply-high by ceil(2^32 / d) is exact while n * d < 2^32 (common.h); otherwise the kernel divides.
+static void ph_epilogue_magic(PhConvParams& p, unsigned long long n_max, int d1, int d2) {
+  const bool ok = d1 > 1 && d2 > 1 && n_max * (unsigned long long)d1 < 0x100000000ull &&
+                  (unsigned long long)d1 * (unsigned long long)d2 < 0x100000000ull;
+  p.magic_e1 = ok ? ph_magic((unsigned)d1) : 0u;
+  p.magic_e2 = ok ? ph_magic((unsigned)d2) : 0u;
+}
+
 // Geometry of the halo kernel for one conv; returns false if the op does not fit it.
 bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
+  p.magic_e1 = p.magic_e2 = 0;
   if (kh == 1 && p.KW == 1) {  // 1x1: halo_mode 2, TAPS = 1 instantiation
     if ((p.cin_read & 31) || p.pool || p.stem || (!has_f32 && p.n_dst < 1)) return false;
     if ((unsigned long long)p.NQ * p.in_Cs * 2ull >= 0xffffffffull ||
@@ -1031,6 +1041,7 @@ bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
     p.PCLIP = 0;
     p.magic_pr = ph_magic(1);
     p.n_mtiles = (p.M + HALO_BM - 1) / HALO_BM;
+    ph_epilogue_magic(p, (unsigned long long)p.n_mtiles * HALO_BM, p.H * p.W, p.W);
     return true;
   }
   if (kh != 3 || p.KW != 3 || (p.cin_read & 31) || has_f32 || p.in_pad < 1 || p.n_dst < 1) return false;
@@ -1053,6 +1064,7 @@ bool ph_conv_halo_plan(PhConvParams& p, int kh, bool has_f32) {
     p.NI = (np_lin + 15) / 16;
     const long long q_last = ((long long)(p.B - 1) * Hp + p.H - 1 + p.in_pad) * Wp + p.W - 1 + p.in_pad;
     p.n_mtiles = (int)((q_last - p.q_first + HALO_BM) / HALO_BM);
+    ph_epilogue_magic(p, (unsigned long long)p.q_first + (unsigned long long)p.n_mtiles * HALO_BM, Hp * Wp, Wp);
   } else {
     p.halo_mode = 1;
     p.tiles_x = (p.W + 15) / 16;
