@@ -1067,6 +1067,10 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
       ph_set_error("decode_v1: limb table entry %d out of range", k);
       return -1;
     }
+  if (!(thr >= 0.f)) {   // the arg-max keys order values by their bit patterns: mask pixels must be positive
+    ph_set_error("decode_v1: conf_thres %g is negative (or NaN); the blob search needs a threshold >= 0", (double)thr);
+    return -1;
+  }
   if (c.run_cap > 65535 || c.kp_cap > 32767) {
     ph_set_error("decode_v1: capacities beyond the 16-bit tables (%d runs, %d blobs)", c.run_cap, c.kp_cap);
     return -1;

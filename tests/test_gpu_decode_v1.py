@@ -161,3 +161,11 @@ def test_capacity_error(engine):
     engine.set_net_out(pred)
     with pytest.raises(PosehipError):
         engine.decode_v1(BODY_PARTS, POSE_PAIRS, MAPIDX, 1, 656, 368, 0.1, kp_cap=4)
+
+
+def test_negative_threshold_is_rejected(engine):
+    """The blob arg-max orders values by their bit patterns, so mask pixels must be positive."""
+    from posehip._ffi import PosehipError
+    engine.set_net_out(np.zeros((1, 57, 46, 82), np.float32))
+    with pytest.raises(PosehipError):
+        engine.decode_v1(BODY_PARTS, POSE_PAIRS, MAPIDX, 1, 656, 368, -0.1)
