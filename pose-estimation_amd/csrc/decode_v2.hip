@@ -25,102 +25,11 @@
 // upsampled map and emits that stripe's peak pixels in raster order.
 // ---------------------------------------------------------------------------
 #define NMS_BAND 8
-#define NMS_TX 256  // block = NMS_TX columns x NMS_TY rows: 16 waves keep the LDS pipeline busy
-#define NMS_TY 4
-#define NMS_TRING 8  // source rows live at once: (NMS_BAND + 2) / scale + 4 taps <= 7 for scale >= 4
-
-__global__ __launch_bounds__(NMS_TX * NMS_TY) void nms_detect_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
-                                                         int Ht, int Wt, float threshold, int max_peaks, int n_parts,
-                                                         int n_split, int rows_per_split, int* __restrict__ keys,
-                                                         int* __restrict__ key_cnt) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int part = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
-  const int tx_ = threadIdx.x, ty_ = threadIdx.y, tid = ty_ * NMS_TX + tx_;
-  constexpr int NT = NMS_TX * NMS_TY;
-  float* s_src = smem;                                   // hs*ws
-  float* s_T = s_src + hs * ws;                          // NMS_TRING * Wt : source row r at slot r & 7
-  float* s_U = s_T + NMS_TRING * Wt;                     // (NMS_BAND+2) * Wt
-  TapsP* s_xt = (TapsP*)(s_U + (NMS_BAND + 2) * Wt);     // Wt
-  int* s_cand = (int*)(s_xt + Wt);                       // (NMS_BAND/2) * (Wt/2+1)
-  int* s_keys = s_cand + (NMS_BAND / 2) * (Wt / 2 + 1);  // max_peaks
-  __shared__ TapsP s_yt[NMS_BAND + 2];
-  __shared__ int s_ncand;
-
-  const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
-  for (int i = tid; i < hs * ws; i += NT) s_src[i] = plane[i];
-  for (int x = tid; x < Wt; x += NT) s_xt[x] = pack_taps(src_taps(x, Wt, ws));
-  if (tid == 0) s_ncand = 0;
-  __syncthreads();
-
-  const int y_begin = sp * rows_per_split;
-  const int y_end = y_begin + rows_per_split < Ht ? y_begin + rows_per_split : Ht;
-  int base = 0;      // peaks found so far in this stripe (uniform across the block)
-  int t_done = -1;   // highest source row already in the T ring
-  for (int r0 = y_begin; r0 < y_end && base < max_peaks; r0 += NMS_BAND) {
-    // output rows needed: [r0-1, r0+NMS_BAND] clamped to the image
-    const int ylo = r0 - 1 < 0 ? 0 : r0 - 1;
-    const int yhi = r0 + NMS_BAND > Ht - 1 ? Ht - 1 : r0 + NMS_BAND;
-    const int nrows_u = yhi - ylo + 1;
-    if (tid < nrows_u) s_yt[tid] = pack_taps(src_taps(ylo + tid, Ht, hs));
-    const int slo = src_taps(ylo, Ht, hs).i0;
-    const int shi = src_taps(yhi, Ht, hs).i3;
-    // 1. horizontal cubic of the source rows not yet in the ring
-    const int t_first = t_done + 1 > slo ? t_done + 1 : slo;
-    for (int x = tx_; x < Wt; x += NMS_TX) {
-      const TapsP tx = s_xt[x];
-      for (int sr = t_first + ty_; sr <= shi; sr += NMS_TY)
-        s_T[(sr & (NMS_TRING - 1)) * Wt + x] = cubic_row(s_src + sr * ws, tx);
-    }
-    t_done = shi;
-    __syncthreads();
-    // 2. vertical cubic -> upsampled band with a 1-row halo
-    for (int x = tx_; x < Wt; x += NMS_TX)
-      for (int rr = ty_; rr < nrows_u; rr += NMS_TY) {
-        const TapsP ty = s_yt[rr];
-        s_U[rr * Wt + x] =
-            cubic(s_T[(ty.i0 & (NMS_TRING - 1)) * Wt + x], s_T[(ty.i1 & (NMS_TRING - 1)) * Wt + x],
-                  s_T[(ty.i2 & (NMS_TRING - 1)) * Wt + x], s_T[(ty.i3 & (NMS_TRING - 1)) * Wt + x], ty.d);
-      }
-    __syncthreads();
-    // 3. strict 3x3 maxima above threshold, 1-px image border excluded
-    const int y_first = r0 < 1 ? 1 : r0;
-    int y_last = r0 + NMS_BAND - 1 > Ht - 2 ? Ht - 2 : r0 + NMS_BAND - 1;
-    y_last = y_last > y_end - 1 ? y_end - 1 : y_last;
-    for (int x = tx_ + 1; x < Wt - 1; x += NMS_TX)
-      for (int y = y_first + ty_; y <= y_last; y += NMS_TY) {
-        const float* u = s_U + (y - ylo) * Wt + x;
-        const float v = u[0];
-        if (v > threshold) {
-          if (v > u[-Wt - 1] && v > u[-Wt] && v > u[-Wt + 1] && v > u[-1] && v > u[1] && v > u[Wt - 1] &&
-              v > u[Wt] && v > u[Wt + 1]) {
-            const int slot = atomicAdd(&s_ncand, 1);
-            s_cand[slot] = y * Wt + x;
-          }
-        }
-      }
-    __syncthreads();
-    // 4. raster order inside the band by rank; keep the first max_peaks of the stripe
-    const int n = s_ncand;
-    for (int i = tid; i < n; i += NT) {
-      const int key = s_cand[i];
-      int rank = 0;
-      for (int j = 0; j < n; j++) rank += s_cand[j] < key;
-      if (base + rank < max_peaks) s_keys[base + rank] = key;
-    }
-    base += n;
-    __syncthreads();
-    if (tid == 0) s_ncand = 0;
-    __syncthreads();
-  }
-  const int count = base < max_peaks ? base : max_peaks;
-  int* out = keys + (((size_t)b * n_parts + part) * n_split + sp) * max_peaks;
-  for (int k = tid; k < count; k += NT) out[k] = s_keys[k];
-  if (tid == 0) key_cnt[((size_t)b * n_parts + part) * n_split + sp] = count;
-}
 
 // ---------------------------------------------------------------------------
-// kernel 1a, column form (the default): same outputs as nms_detect_kernel, no upsampled pixel ever goes through
-// LDS.  A lane owns one output column and walks down the stripe: the four horizontally interpolated source rows
+// kernel 1a, column form: no upsampled pixel ever goes through LDS (the first form staged upsampled 8-row bands
+// in LDS and took 0.50 ms per 32 frames against 0.27 ms; removed in round 2).  A lane owns one output column and
+// walks down the stripe: the four horizontally interpolated source rows
 // of the current vertical taps and the cubic's coefficients live in registers (they change once per source row,
 // i.e. every `scale` output rows), an output pixel is the 8 fp32 operations of the cubic in d -- the very
 // operations of cubic(), so results are bit-identical -- and the 3x3 test takes the column maxima of the two
@@ -1405,19 +1314,15 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   const float nms_offset = (float)(0.5 / (double)scale);
   const int n_split = PH_V2_NMS_SPLIT;
   const int rows_per_split = (((Ht + n_split - 1) / n_split) + NMS_BAND - 1) / NMS_BAND * NMS_BAND;
-  // POSEHIP_NMS_BANDS=1: the first form of kernel 1a (upsampled bands through LDS), kept for A/B runs
-  static const bool nms_bands = [] { const char* e = getenv("POSEHIP_NMS_BANDS"); return e && atoi(e) != 0; }();
   const int n_groups = (Wt - 1 + NMS_COLS - 1) / NMS_COLS;          // 62 output columns per wave and group
   const int nms_g = n_groups <= 16 ? 1 : (n_groups <= 32 ? 2 : 4);
   const int nms_waves = (n_groups + nms_g - 1) / nms_g;
-  if (!nms_bands && nms_waves > 16) {
+  if (nms_waves > 16) {
     ph_set_error("decode_v2: target width %d beyond the NMS kernel's %d columns", Wt, 64 * NMS_COLS);
     return -1;
   }
-  const size_t lds1 = nms_bands ? ((size_t)hs * ws + (size_t)NMS_TRING * Wt + (size_t)(NMS_BAND + 2) * Wt) * 4 +
-                          (size_t)Wt * sizeof(TapsP) + ((size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4
-                                : (size_t)hs * ws * 4 + (size_t)(rows_per_split + 2) * sizeof(TapsP) +
-                          ((size_t)(rows_per_split + 3) + (size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4;
+  const size_t lds1 = (size_t)hs * ws * 4 + (size_t)(rows_per_split + 2) * sizeof(TapsP) +
+                      ((size_t)(rows_per_split + 3) + (size_t)(NMS_BAND / 2) * (Wt / 2 + 1) + m.max_peaks) * 4;
   const size_t lds1b = (size_t)hs * ws * 4;
   // PAF planes in LDS as cubic coefficient tables (16 B per source pixel and channel) when they fit, else raw
   // (POSEHIP_PAF_RAW=1 forces the raw form for A/B runs)
@@ -1452,8 +1357,7 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   static int attr[4][PH_MAX_DEVICES];
   static int attr_c[5][PH_MAX_DEVICES];
   static int attr_m[PH_MAX_DEVICES];
-  if (ph_ensure_lds((const void*)nms_detect_kernel, (int)lim, attr[0]) ||
-      ph_ensure_lds((const void*)nms_detect_cols_kernel<1>, (int)lim, attr_c[0]) ||
+  if (ph_ensure_lds((const void*)nms_detect_cols_kernel<1>, (int)lim, attr_c[0]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<2>, (int)lim, attr_c[1]) ||
       ph_ensure_lds((const void*)nms_detect_cols_kernel<4>, (int)lim, attr_c[2]) ||
       ph_ensure_lds((const void*)nms_refine_kernel, (int)lim, attr[1]) ||
@@ -1469,11 +1373,7 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   PH_CHECK(hipMemsetAsync(w.overflow, 0, sizeof(int), stream));
   if (m.connector == 1) PH_CHECK(hipMemsetAsync(w.n_accept, 0, sz.n_accept, stream));
   if (ev) PH_CHECK(hipEventRecord(ev[0], stream));
-  if (nms_bands) {
-    hipLaunchKernelGGL(nms_detect_kernel, dim3(m.n_parts, B, n_split), dim3(NMS_TX, NMS_TY), lds1, stream, net_out, C,
-                       hs, ws, Ht, Wt, m.nms_threshold, m.max_peaks, m.n_parts, n_split, rows_per_split, w.nms_keys,
-                       w.nms_cnt);
-  } else {
+  {
     auto kern = nms_g == 1 ? nms_detect_cols_kernel<1> : (nms_g == 2 ? nms_detect_cols_kernel<2> : nms_detect_cols_kernel<4>);
     hipLaunchKernelGGL(kern, dim3(m.n_parts, B, n_split), dim3(64 * nms_waves), lds1, stream, net_out, C, hs, ws, Ht,
                        Wt, m.nms_threshold, m.max_peaks, m.n_parts, n_split, rows_per_split, n_groups, w.nms_keys,
