@@ -5,7 +5,8 @@
 
 V2 decode (both connectors) on synthetic people at random sizes / scales / crowding and on smoothed-noise maps
 (hundreds of peaks, thousands of accepted pairs: exact ties, merges, conflicts); V1 decode on people and on
-noise-topology heat maps (rings, nested islands, ragged blobs).  Everything is compared bit for bit, as in the
+noise-topology heat maps (rings, nested islands, ragged blobs); both preprocess flavours at random source and net
+sizes.  Everything is compared bit for bit, as in the
 -m gpu tests; the first mismatch prints its recipe and the script exits 1.
 """
 import argparse
@@ -101,6 +102,33 @@ def v1_case(eng, seed):
     return recipe + f" -> {rk.shape[0]} keypoints, {len(rp)} people"
 
 
+def pre_case(eng, seed):
+    """Both preprocess flavours at random source / net sizes (down-scales, up-scales -> cubic, ragged margins)."""
+    from oracle import preprocess as pre_ref
+    from posehip import _ffi, caffe_io, graph
+    rng = np.random.default_rng(seed)
+    Hn, Wn = 16 * int(rng.integers(4, 24)), 16 * int(rng.integers(4, 42))
+    if rng.random() < 0.3:     # an up-scale
+        H0, W0 = int(rng.integers(20, Hn)), int(rng.integers(20, Wn))
+    else:
+        H0, W0 = int(rng.integers(Hn // 2, 3 * Hn + 2)), int(rng.integers(Wn // 2, 3 * Wn + 2))
+    frames = synth.synth_frames(seed, 1, H0, W0)
+    net = caffe_io.parse_prototxt(f'input: "image" input_dim: 1 input_dim: 3 input_dim: {Hn} input_dim: {Wn}\n' +
+                                  caffe_io._conv("out", "image", 8, 3))
+    eng.build(graph.build_plan(net, graph.random_weights(net, 0)), 1)
+    recipe = f"PRE seed={seed} source {H0}x{W0} -> net {Hn}x{Wn}"
+    eng.preprocess(frames, _ffi.PH_PRE_NATIVE)
+    got = eng.get_buffer(0)[:, 1:-1, 1:-1, :3]
+    want = pre_ref.cv_mat_to_op_input(frames, Wn, Hn).transpose(0, 2, 3, 1)
+    assert np.array_equal(got, want), recipe + f": native flavour, {int((got != want).sum())} values differ"
+    eng.preprocess(frames, _ffi.PH_PRE_CV2)
+    got = eng.get_buffer(0)[:, 1:-1, 1:-1, :3]
+    ref = pre_ref.cv_resize_u8(frames, Wn, Hn).astype(np.float32) * np.float32(1 / 255.0)
+    ref16 = ((ref.view(np.uint32) + 0x7fff + ((ref.view(np.uint32) >> 16) & 1)) >> 16 << 16).astype(np.uint32)
+    assert np.array_equal(got.view(np.uint32), ref16), recipe + ": cv2 flavour"
+    return recipe + " ok"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=8.0)
@@ -108,10 +136,10 @@ def main():
     args = ap.parse_args()
     eng = Engine(0)
     t_end = time.time() + args.minutes * 60
-    n = {"V1": 0, "V2": 0}
+    n = {"V1": 0, "V2": 0, "PRE": 0}
     seed = args.seed0
     while time.time() < t_end:
-        for fn, key in ((v2_case, "V2"), (v1_case, "V1")):
+        for fn, key in ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE")):
             try:
                 msg = fn(eng, seed)
             except AssertionError as e:
@@ -120,7 +148,7 @@ def main():
             n[key] += 1
             print(msg, flush=True)
         seed += 1
-    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, seeds {args.seed0}..{seed - 1}", flush=True)
+    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, seeds {args.seed0}..{seed - 1}", flush=True)
 
 
 if __name__ == "__main__":
