@@ -372,6 +372,8 @@ __device__ int v1_trace(const V1Grid& g, int x0, int y0, bool is_hole, unsigned 
       mark[j3] = cid;
       ok = verts.push(0, make_short2((short)x0, (short)y0));
     }
+    verts.base = __shfl(verts.base, 0, 8);
+    __threadfence_block();
     return __shfl(ok, 0, 8) ? 1 : -1;
   }
   s = (s_end - __ffs(hit)) & 7;
