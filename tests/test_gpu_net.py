@@ -60,6 +60,10 @@ CASES = {
     # single-chunk K loops: 1x1 over 32 channels (one K step), 3x3 over 32 channels (one patch, nine steps)
     "one_chunk": (20, 36, [("conv", "a", "image", 32, 3, "ReLU"), ("conv", "b", "a", 40, 3, "PReLU"),
                             ("conv", "c", "b", 32, 1, "ReLU"), ("conv", "out", "c", 20, 1, None)]),
+    # 1x1 layers on a large map: the epilogue's row table divides by precomputed reciprocals at batch 1 and falls
+    # back to real divisions at batch 3 (pixel index x image size beyond 2^32: conv_mfma.hip, ph_epilogue_magic)
+    "big_1x1": (200, 300, [("conv", "c1", "image", 32, 3, "ReLU"), ("conv", "c2", "c1", 32, 1, "PReLU"),
+                            ("conv", "out", "c2", 20, 1, None)]),
     "odd_pool": (13, 19, [("conv", "c1", "image", 64, 3, "ReLU"), ("pool", "p", "c1"),
                            ("conv", "out", "p", 38, 3, None)]),
 }
