@@ -326,9 +326,11 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
         return -1;
       }
       const Buf& ob = c->bufs[d.dst_buf[0]];
-      if (ob.d.channels != in.d.channels || ob.d.height != (in.d.height + 1) / 2 ||
-          ob.d.width != (in.d.width + 1) / 2) {
-        ph_set_error("ph_net_build: op %d: pool geometry mismatch", i);
+      // the pooled map may be one member of a wider (concat) buffer: an 8-aligned channel window of it
+      if (d.dst_coff[0] < 0 || (d.dst_coff[0] & 7) || d.dst_coff[0] + in.d.channels > ob.d.channels ||
+          ob.d.height != (in.d.height + 1) / 2 || ob.d.width != (in.d.width + 1) / 2) {
+        ph_set_error("ph_net_build: op %d: pool geometry mismatch (%dx%dx%d -> window %d of %dx%dx%d)", i, in.d.height,
+                     in.d.width, in.d.channels, d.dst_coff[0], ob.d.height, ob.d.width, ob.d.channels);
         return -1;
       }
       continue;
@@ -586,7 +588,7 @@ static int run_ops(ph_ctx* c, int B, bool timed) {
       const Buf& ob = c->bufs[o.d.dst_buf[0]];
       if (ph_launch_maxpool(in.ptr, ob.ptr, B, in.d.height, in.d.width, in.d.channels, in.Hp(), in.Wp(),
                             in.d.channels, in.org(0, 0), ob.d.height, ob.d.width, ob.Hp(), ob.Wp(), ob.d.channels,
-                            ob.org(0, 0), c->stream))
+                            ob.org(0, o.d.dst_coff[0]), c->stream))
         return -1;
     } else {
       o.cp.B = B;

@@ -309,6 +309,9 @@ def build_plan(net, weights, height=None, width=None, tile_overrides=None, fuse_
             plan.op_names.append(n.name)
         elif n.kind == "pool":
             src = n.src[0]
+            if not src.views:
+                raise ValueError(f"layer {n.name!r}: pooling input {src.name!r} has no buffer of its own "
+                                 f"(a Concat cannot be pooled)")
             b, coff = src.views[0]
             if coff != 0 or plan.bufs[b]["channels"] != _r8(src.cout) or len(n.views) != 1:
                 # pooling reads/writes whole buffers; give the source its own

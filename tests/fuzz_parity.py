@@ -6,7 +6,8 @@
 V2 decode (both connectors) on synthetic people at random sizes / scales / crowding and on smoothed-noise maps
 (hundreds of peaks, thousands of accepted pairs: exact ties, merges, conflicts); V1 decode on people and on
 noise-topology heat maps (rings, nested islands, ragged blobs); both preprocess flavours at random source and net
-sizes.  Everything is compared bit for bit, as in the
+sizes; random small Caffe graphs through the plan builder and the conv kernels (< 1e-2 of the fp32 oracle with bf16
+storage emulated).  Everything else is compared bit for bit, as in the
 -m gpu tests; the first mismatch prints its recipe and the script exits 1.
 """
 import argparse
@@ -129,17 +130,88 @@ def pre_case(eng, seed):
     return recipe + " ok"
 
 
+def net_case(eng, seed):
+    """A random small Caffe graph (3x3 / 1x1 / 7x7 convs, ReLU / PReLU, 2x2 pools, concats of same-size blobs,
+    odd channel counts and map sizes) through graph.build_plan + the conv kernels vs the torch fp32 oracle."""
+    from oracle import net_ref
+    from posehip import _ffi, caffe_io, graph
+    rng = np.random.default_rng(seed)
+    h, w = int(rng.integers(9, 70)), int(rng.integers(9, 180))
+    txt = f'input: "image"\ninput_dim: 1\ninput_dim: 3\ninput_dim: {h}\ninput_dim: {w}\n'
+    widths = [8, 16, 19, 26, 32, 38, 40, 52, 64, 96, 128, 160]
+    blobs = [("image", 3, 0)]          # (name, channels, pooling level)
+    level, desc = 0, []
+    n_layers = int(rng.integers(2, 8))
+    for i in range(n_layers):
+        same = [b for b in blobs if b[2] == level and b[0] != "image"]
+        kind = rng.random()
+        plain = [b for b in same if not b[0].startswith("cat")]   # (the planner rejects a concat of concats, loudly)
+        if kind < 0.15 and len(plain) >= 2:
+            k = int(rng.integers(2, min(4, len(plain)) + 1))
+            members = [plain[j] for j in sorted(rng.choice(len(plain), k, replace=False))]
+            name = f"cat{i}"
+            txt += caffe_io._concat(name, [m[0] for m in members])
+            blobs.append((name, sum(m[1] for m in members), level))
+            desc.append(f"concat{[m[1] for m in members]}")
+            continue
+        bottom = blobs[-1] if blobs[-1][2] == level else same[-1]
+        if kind < 0.3 and bottom[0] != "image" and (h >> level) >= 6 and (w >> level) >= 6:
+            name = f"p{i}"
+            txt += caffe_io._pool(name, bottom[0])
+            level += 1
+            blobs.append((name, bottom[1], level))
+            desc.append("pool")
+            continue
+        cout = int(rng.choice(widths))
+        k = int(rng.choice([3, 3, 3, 1, 1, 7])) if bottom[0] != "image" else 3
+        name = f"c{i}"
+        txt += caffe_io._conv(name, bottom[0], cout, k)
+        act = [None, "ReLU", "PReLU"][int(rng.integers(0, 3))]
+        if act:
+            txt += caffe_io._act(act, "a" + name, name)
+        blobs.append((name, cout, level))
+        desc.append(f"conv{k}x{k}:{bottom[1]}->{cout}{'+' + act if act else ''}")
+    last = blobs[-1] if blobs[-1][0] != "image" else None
+    if last is None or last[0].startswith("p") or last[0].startswith("cat"):
+        txt += caffe_io._conv("out", blobs[-1][0], int(rng.choice([8, 19, 26])), 1 if blobs[-1][0] != "image" else 3)
+        desc.append("conv:out")
+    batch = int(rng.integers(1, 4))
+    recipe = f"NET seed={seed} {h}x{w} batch={batch} " + " ".join(desc)
+    net = caffe_io.parse_prototxt(txt)
+    weights = graph.random_weights(net, seed=seed, out_gain=1.0)
+    try:
+        plan = graph.build_plan(net, weights)
+    except ValueError as e:      # a graph shape the planner refuses by design (pooled concat, ...): loud, not wrong
+        return recipe + f" -> refused by the planner ({e})"
+    eng.build(plan, batch)
+    x = rng.integers(0, 256, (batch, h, w, 3), dtype=np.uint8)
+    B = eng.preprocess(x, _ffi.PH_PRE_CV2)
+    eng.forward(B)
+    got = eng.net_out(B)
+    xf = x.astype(np.float32).transpose(0, 3, 1, 2) * np.float32(1.0 / 255.0)
+    ref16 = net_ref.forward(net, weights, xf, bf16_sim=True)
+    assert got.shape == ref16.shape, recipe + f": shape {got.shape} vs {ref16.shape}"
+    scale = float(np.abs(ref16).max()) + 1e-6
+    err = float(np.abs(got - ref16).max()) / scale
+    assert np.isfinite(got).all() and err < 1e-2, recipe + f": relative error {err:.3e}"
+    return recipe + f" -> err {err:.1e}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=8.0)
     ap.add_argument("--seed0", type=int, default=0)
+    ap.add_argument("--only", type=str, default="", help="comma list of V2,V1,PRE,NET")
     args = ap.parse_args()
     eng = Engine(0)
     t_end = time.time() + args.minutes * 60
-    n = {"V1": 0, "V2": 0, "PRE": 0}
+    n = {"V1": 0, "V2": 0, "PRE": 0, "NET": 0}
     seed = args.seed0
     while time.time() < t_end:
-        for fn, key in ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE")):
+        cases = ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE"), (net_case, "NET"))
+        if args.only:
+            cases = tuple(c for c in cases if c[1] in args.only.split(","))
+        for fn, key in cases:
             try:
                 msg = fn(eng, seed)
             except AssertionError as e:
@@ -148,7 +220,7 @@ def main():
             n[key] += 1
             print(msg, flush=True)
         seed += 1
-    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, seeds {args.seed0}..{seed - 1}", flush=True)
+    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, {n['NET']} network cases, seeds {args.seed0}..{seed - 1}", flush=True)
 
 
 if __name__ == "__main__":

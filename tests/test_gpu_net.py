@@ -64,6 +64,11 @@ CASES = {
     # back to real divisions at batch 3 (pixel index x image size beyond 2^32: conv_mfma.hip, ph_epilogue_magic)
     "big_1x1": (200, 300, [("conv", "c1", "image", 32, 3, "ReLU"), ("conv", "c2", "c1", 32, 1, "PReLU"),
                             ("conv", "out", "c2", 20, 1, None)]),
+    # a pooled map that is a member of a concat: the pool op writes a channel window of the wider buffer
+    # (found by tests/fuzz_parity.py; not a shape the OpenPose graphs use)
+    "pool_into_concat": (17, 30, [("conv", "c0", "image", 38, 3, "PReLU"), ("pool", "p1", "c0"),
+                                   ("conv", "c2", "p1", 8, 1, None), ("concat", "cat3", ["p1", "c2"]),
+                                   ("conv", "c4", "cat3", 128, 3, None), ("conv", "out", "c4", 40, 7, None)]),
     "odd_pool": (13, 19, [("conv", "c1", "image", 64, 3, "ReLU"), ("pool", "p", "c1"),
                            ("conv", "out", "p", 38, 3, None)]),
 }

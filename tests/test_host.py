@@ -115,6 +115,14 @@ def test_unsupported_graphs_are_rejected():
                                   'layer { name: "s" type: "Softmax" bottom: "image" top: "s" }')
     with pytest.raises(ValueError):
         graph.build_plan(bad, {})
+    # a pooled Concat and a Concat of Concats have no buffer layout here: refused with a message, not an IndexError
+    head = ('input: "image" input_dim: 1 input_dim: 3 input_dim: 8 input_dim: 8\n' + caffe_io._conv("a", "image", 8, 3) +
+            caffe_io._conv("b", "a", 8, 3) + caffe_io._concat("cat", ["a", "b"]))
+    for tail in (caffe_io._pool("p", "cat") + caffe_io._conv("out", "p", 8, 1),
+                 caffe_io._conv("c", "cat", 8, 3) + caffe_io._concat("cat2", ["cat", "c"]) + caffe_io._conv("out", "cat2", 8, 1)):
+        net = caffe_io.parse_prototxt(head + tail)
+        with pytest.raises(ValueError):
+            graph.build_plan(net, graph.random_weights(net, 0))
 
 
 def test_net_input_size():
