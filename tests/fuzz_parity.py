@@ -197,18 +197,71 @@ def net_case(eng, seed):
     return recipe + f" -> err {err:.1e}"
 
 
+def post_case(eng, seed):
+    """What the estimator derives from the keypoints on the device: torso boxes, depth lift (fp64), heat-map export
+    under --heatmaps_scale, and the tracker feature (crop under the torso box + resize_tensor), all bit for bit."""
+    from oracle import features, post_v2
+    from posehip.tables import TORSO_IDS
+    rng = np.random.default_rng(seed)
+    hs, ws = [(46, 82), (46, 46), (23, 31)][int(rng.integers(0, 3))]
+    Ht, Wt = hs * 8, ws * 8
+    B = int(rng.integers(1, 4))
+    people = [int(rng.integers(0, 9)) for _ in range(B)]
+    net = np.stack([synth.synth_net_output(seed * 7 + i, people[i], BODY_25, hs, ws) for i in range(B)])
+    eng.set_net_out(net)
+    H0, W0 = int(rng.integers(Ht, 3 * Ht)), int(rng.integers(Wt, 3 * Wt))
+    scale = float(rng.choice([1.0, H0 / Ht, 2.9433]))
+    recipe = f"POST seed={seed} net {hs}x{ws} B={B} people={people} image {H0}x{W0} scale={scale:.4f}"
+    res, ex = eng.decode_v2(BODY_25, B, Ht, Wt, scale, 128)
+    depth = rng.integers(0, 6000, (B, H0, W0), dtype=np.uint16)
+    depth[rng.random(depth.shape) < 0.05] = 0                      # holes in the depth image
+    intr = (float(rng.uniform(500, 1200)), float(rng.uniform(500, 1200)), W0 / 2 + float(rng.uniform(-20, 20)),
+            H0 / 2 + float(rng.uniform(-20, 20)))
+    patch = int(rng.integers(0, 4))
+    bbox, kp3d = eng.pose_post(B, 128, BODY_25.n_parts, TORSO_IDS, depth, intr, 1e-3, patch)
+    counts = []
+    for b in range(B):
+        kp = res[b][0]
+        m = len(kp)
+        counts.append(m)
+        assert np.array_equal(bbox[b, :m], post_v2.torso_bbox(kp, TORSO_IDS)), recipe + f": torso boxes frame {b}"
+        for q in range(m):
+            want = post_v2.lift_3d(kp[q], depth[b], *intr, 1e-3, patch)
+            assert np.array_equal(kp3d[b, q].view(np.uint64), want.view(np.uint64)), recipe + f": 3-D lift {b}/{q}"
+    mode = int(rng.integers(0, 4))
+    windows = [[(0, 25)], [(0, 25), (25, 1), (26, 52)], [(26, 52)], [(3, 9), (25, 1)]][int(rng.integers(0, 4))]
+    size = [(25, 50), (7, 4), (13, 31)][int(rng.integers(0, 3))]
+    if sum(counts):
+        feat, status = eng.pose_features(B, 128, BODY_25.n_parts, TORSO_IDS, windows, BODY_25.n_heat, mode, Ht, Wt,
+                                         (W0, H0), sum(counts), size)
+        row = 0
+        for b in range(B):
+            if not counts[b]:
+                continue
+            hm = np.moveaxis(features.export_heatmaps(net[b], windows, BODY_25.n_heat, mode, Ht, Wt), 0, -1)
+            want = features.detection_features(post_v2.torso_bbox(res[b][0], TORSO_IDS), hm, (W0, H0), size)
+            for w in want:
+                if isinstance(w, Exception):
+                    assert status[row] == -1 and not feat[row].any(), recipe + f": feature row {row} should be refused"
+                else:
+                    assert status[row] == 1 and np.array_equal(feat[row].reshape(-1).astype(np.float64), w), \
+                        recipe + f": feature row {row} mode {mode} windows {windows} size {size}"
+                row += 1
+    return recipe + f" -> {sum(counts)} people, mode {mode}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=8.0)
     ap.add_argument("--seed0", type=int, default=0)
-    ap.add_argument("--only", type=str, default="", help="comma list of V2,V1,PRE,NET")
+    ap.add_argument("--only", type=str, default="", help="comma list of V2,V1,PRE,NET,POST")
     args = ap.parse_args()
     eng = Engine(0)
     t_end = time.time() + args.minutes * 60
-    n = {"V1": 0, "V2": 0, "PRE": 0, "NET": 0}
+    n = {"V1": 0, "V2": 0, "PRE": 0, "NET": 0, "POST": 0}
     seed = args.seed0
     while time.time() < t_end:
-        cases = ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE"), (net_case, "NET"))
+        cases = ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE"), (net_case, "NET"), (post_case, "POST"))
         if args.only:
             cases = tuple(c for c in cases if c[1] in args.only.split(","))
         for fn, key in cases:
@@ -220,7 +273,7 @@ def main():
             n[key] += 1
             print(msg, flush=True)
         seed += 1
-    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, {n['NET']} network cases, seeds {args.seed0}..{seed - 1}", flush=True)
+    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, {n['NET']} network cases, {n['POST']} post-processing cases, seeds {args.seed0}..{seed - 1}", flush=True)
 
 
 if __name__ == "__main__":
