@@ -250,18 +250,67 @@ def post_case(eng, seed):
     return recipe + f" -> {sum(counts)} people, mode {mode}"
 
 
+def movenet_case(eng, seed):
+    """MoveNet steps around the model: crop_and_resize (int32), coordinate update + next crop region (float64), and
+    the MultiPose head decode, at random sizes / regions / scores."""
+    from oracle import movenet as omv
+    from posehip import movenet as mv
+    rng = np.random.default_rng(seed)
+    B = int(rng.integers(1, 6))
+    ih, iw = int(rng.integers(40, 300)), int(rng.integers(40, 400))
+    frames = rng.integers(0, 256, (B, ih, iw, 3), dtype=np.uint8)
+    regions = []
+    for b in range(B):
+        if rng.random() < 0.3:
+            regions.append(omv.init_crop_region(ih, iw))
+        else:
+            y0, x0 = rng.uniform(-0.4, 0.7, 2)
+            side = rng.uniform(0.1, 1.4)
+            asp = rng.uniform(0.5, 1.5)
+            regions.append({'y_min': y0, 'x_min': x0, 'y_max': y0 + side, 'x_max': x0 + side * asp, 'height': side,
+                            'width': side * asp})
+    size = int(rng.integers(1, 70))
+    recipe = f"MOVENET seed={seed} B={B} image {ih}x{iw} crop {size}"
+    got = mv.crop_and_resize_batch(frames, regions, (size, size))
+    for b in range(B):
+        assert np.array_equal(got[b], omv.crop_and_resize(frames[b], regions[b], (size, size))), recipe + f": crop {b}"
+    k = rng.uniform(-0.1, 1.1, (B, 1, 17, 3)).astype(np.float32)
+    k[:, :, :, 2] = rng.choice([0.0, 0.05, 0.19, 0.2, 0.21, 0.6, 0.95], (B, 1, 17)).astype(np.float32)
+    got_k, got_r = mv.update_and_determine_batch(k, regions, ih, iw)
+    for b in range(B):
+        want_k = omv.update_keypoints(k[b:b + 1], regions[b], ih, iw)
+        assert np.array_equal(got_k[b:b + 1].view(np.uint32), want_k.view(np.uint32)), recipe + f": keypoints {b}"
+        want_r = omv.determine_crop_region(want_k, ih, iw)
+        for key in want_r:
+            assert np.float64(got_r[b][key]).view(np.uint64) == np.float64(want_r[key]).view(np.uint64), \
+                recipe + f": crop region {b} {key}"
+    G, P = int(rng.integers(4, 70)), int(rng.integers(1, 13))
+    Bm = int(rng.integers(1, 4))
+    center = rng.uniform(0, 1, (Bm, G, G)).astype(np.float32) ** int(rng.integers(1, 6))
+    heat = rng.uniform(0, 1, (Bm, G, G, 17)).astype(np.float32)
+    regr = rng.normal(0, G / 8, (Bm, G, G, 34)).astype(np.float32)
+    offs = rng.uniform(-0.5, 0.5, (Bm, G, G, 34)).astype(np.float32)
+    box = rng.uniform(1, G / 2 + 1, (Bm, G, G, 2)).astype(np.float32)
+    thr = float(rng.choice([0.1, 0.3, 0.9]))
+    gotd = mv.multipose_decode(center, heat, regr, offs, box, P, thr)
+    for b in range(Bm):
+        want = omv.multipose_decode(center[b], heat[b], regr[b], offs[b], box[b], P, thr)
+        assert np.array_equal(gotd[b].view(np.uint32), want.view(np.uint32)), recipe + f": head decode {b} G={G} P={P} thr={thr}"
+    return recipe + f" G={G} P={P} ok"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=8.0)
     ap.add_argument("--seed0", type=int, default=0)
-    ap.add_argument("--only", type=str, default="", help="comma list of V2,V1,PRE,NET,POST")
+    ap.add_argument("--only", type=str, default="", help="comma list of V2,V1,PRE,NET,POST,MOVENET")
     args = ap.parse_args()
     eng = Engine(0)
     t_end = time.time() + args.minutes * 60
-    n = {"V1": 0, "V2": 0, "PRE": 0, "NET": 0, "POST": 0}
+    n = {"V1": 0, "V2": 0, "PRE": 0, "NET": 0, "POST": 0, "MOVENET": 0}
     seed = args.seed0
     while time.time() < t_end:
-        cases = ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE"), (net_case, "NET"), (post_case, "POST"))
+        cases = ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE"), (net_case, "NET"), (post_case, "POST"), (movenet_case, "MOVENET"))
         if args.only:
             cases = tuple(c for c in cases if c[1] in args.only.split(","))
         for fn, key in cases:
@@ -273,7 +322,7 @@ def main():
             n[key] += 1
             print(msg, flush=True)
         seed += 1
-    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, {n['NET']} network cases, {n['POST']} post-processing cases, seeds {args.seed0}..{seed - 1}", flush=True)
+    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, {n['NET']} network cases, {n['POST']} post-processing cases, {n['MOVENET']} MoveNet cases, seeds {args.seed0}..{seed - 1}", flush=True)
 
 
 if __name__ == "__main__":
