@@ -1315,7 +1315,10 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   const int n_split = PH_V2_NMS_SPLIT;
   const int rows_per_split = (((Ht + n_split - 1) / n_split) + NMS_BAND - 1) / NMS_BAND * NMS_BAND;
   const int n_groups = (Wt - 1 + NMS_COLS - 1) / NMS_COLS;          // 62 output columns per wave and group
-  const int nms_g = n_groups <= 16 ? 1 : (n_groups <= 32 ? 2 : 4);
+  static const int nms_g_env = [] { const char* e = getenv("POSEHIP_NMS_G"); return e ? atoi(e) : 0; }();
+  // two columns per lane from 8 groups on: the two independent cubics pair up into packed fp32 operations
+  // (0.29 vs 0.33 ms per 32 frames at 656 columns; four per lane is no faster).  POSEHIP_NMS_G overrides.
+  const int nms_g = nms_g_env ? nms_g_env : (n_groups <= 7 ? 1 : (n_groups <= 32 ? 2 : 4));
   const int nms_waves = (n_groups + nms_g - 1) / nms_g;
   if (nms_waves > 16) {
     ph_set_error("decode_v2: target width %d beyond the NMS kernel's %d columns", Wt, 64 * NMS_COLS);
