@@ -51,6 +51,31 @@ def _write_image(path: str, bgr: np.ndarray) -> None:
     Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(path)
 
 
+class _FrameSkipped(Exception):
+    """A frame that cannot go through the estimator: the cause and the warning lines the
+    reference prints for it (``inference.py:208-215,237-247,271-278``)."""
+
+    def __init__(self, cause, *lines):
+        super().__init__(cause)
+        self.cause, self.lines = cause, lines
+
+    def report(self):
+        print(self.cause)
+        for line in self.lines:
+            print(line)
+
+
+def _fetch(src, reader):
+    """A source given as a path goes through `reader`; an array is taken as it is."""
+    if not isinstance(src, str):
+        assert isinstance(src, np.ndarray)
+        return src
+    try:
+        return reader(src)
+    except Exception as cause:
+        raise _FrameSkipped(cause, f"[WARN] : Error loading data, skipping {src}") from cause
+
+
 def extract_2dskeletons(args: argparse.Namespace,
                         pose_extractor: OpenPosePoseExtractor,
                         color_src: Union[np.ndarray, str],
@@ -71,58 +96,32 @@ def extract_2dskeletons(args: argparse.Namespace,
     unless ``op_save_skel`` is off *and* nobody is found); it is kept, not repaired.
     """
     assert color_src is not None
-
-    with Timer("data preparation", enable_timer, printout=False) as t1:
-        paths = prepare_save_paths(skeleton_folder, skeleton_file_prefix, args.op_save_skel,
-                                   args.op_save_skel_image, args.op_save_3d_skel)
-        if isinstance(color_src, str):
+    # second warning line of the reshape / inference failures: only a file has a name to print
+    origin = (f"skipping {color_src}",) if isinstance(color_src, str) else ()
+    lift = bool(args.op_extract_3d_skel)
+    try:
+        with Timer("data preparation", enable_timer, printout=False) as prep:
+            paths = prepare_save_paths(skeleton_folder, skeleton_file_prefix, args.op_save_skel,
+                                       args.op_save_skel_image, args.op_save_3d_skel)
+            image = _fetch(color_src, read_color_file)
+            depth = _fetch(depth_src, read_depth_file) if lift and depth_src is not None else None
+            try:  # the estimator takes exactly H x W x 3 (SURVEY appendix B.12)
+                image = image.reshape(args.op_image_height, args.op_image_width, 3)
+            except Exception as cause:
+                raise _FrameSkipped(cause, "[WARN] : Error in reshaping image...", *origin) from cause
+        with Timer("infer", enable_timer, printout=False) as infer:
+            csv_2d, csv_3d, jpg = paths['skel_save_path'], paths['3dskel_save_path'], paths['skel_image_save_path']
             try:
-                image = read_color_file(color_src)
-            except Exception as e:
-                print(e)
-                print(f"[WARN] : Error loading data, skipping {color_src}")
-                return dict(_FAILED)
-        else:
-            assert isinstance(color_src, np.ndarray)
-            image = color_src
-
-        depth = None
-        if args.op_extract_3d_skel and depth_src is not None:
-            if isinstance(depth_src, str):
-                try:
-                    depth = read_depth_file(depth_src)
-                except Exception as e:
-                    print(e)
-                    print(f"[WARN] : Error loading data, skipping {depth_src}")
-                    return dict(_FAILED)
-            else:
-                assert isinstance(depth_src, np.ndarray)
-                depth = depth_src
-
-        try:
-            image = image.reshape(args.op_image_height, args.op_image_width, 3)
-        except Exception as e:
-            print(e)
-            print("[WARN] : Error in reshaping image...")
-            if isinstance(color_src, str):
-                print(f"skipping {color_src}")
-            return dict(_FAILED)
-
-    with Timer("infer", enable_timer, printout=False) as t2:
-        try:
-            if args.op_extract_3d_skel:
-                pose_extractor.predict_3d(image, depth, intr_mat, paths['skel_save_path'],
-                                          paths['3dskel_save_path'], paths['skel_image_save_path'])
-            else:
-                pose_extractor.predict(image, depth, paths['skel_save_path'], paths['skel_image_save_path'])
-        except Exception as e:
-            print(e)
-            print("[WARN] : Error in pose extraction...")
-            if isinstance(color_src, str):
-                print(f"skipping {color_src}")
-            return dict(_FAILED)
-
-    return {'status': True, 'data_prep_time': t1.duration, 'infer_time': t2.duration}
+                if lift:
+                    pose_extractor.predict_3d(image, depth, intr_mat, csv_2d, csv_3d, jpg)
+                else:
+                    pose_extractor.predict(image, depth, csv_2d, jpg)
+            except Exception as cause:
+                raise _FrameSkipped(cause, "[WARN] : Error in pose extraction...", *origin) from cause
+    except _FrameSkipped as skipped:
+        skipped.report()
+        return dict(_FAILED)
+    return {'status': True, 'data_prep_time': prep.duration, 'infer_time': infer.duration}
 
 
 class ExtractSkeletonAndTrack:
@@ -133,28 +132,33 @@ class ExtractSkeletonAndTrack:
     queue_output() -> (filtered_skel, prep_time, infer_time, track_time, break_loop)
 
     ``break_process_loops()`` sends the sentinel through all three stages and waits for it.
+
+    Every queue carries tuples whose LAST field is the stop flag; the layouts between the stages
+    are the reference's (``:83-116``, ``:120-146``, ``:150-165``).  One pump (`_pump`) serves all
+    three threads: it forwards the sentinel, padded to the next layout's width, and otherwise
+    hands the tuple's fields to the stage function.
     """
+    _MP_MESSAGE = "mp not supported for now, openpose inference seems to cause the mp to hang."
 
     def __init__(self, args, pose_extractor, tracker, enable_timer) -> None:
         self.args = args
         self.PE = pose_extractor
         self.TK = tracker
         self.enable_timer = enable_timer
-        if args.op_proc == 'mp':
-            raise ValueError("mp not supported for now, openpose inference seems to cause the mp to hang.")
-        self.infer_queue = Queue(maxsize=10)
-        self.track_queue = Queue(maxsize=10)
-        self.write_queue = Queue(maxsize=10)
-        self.final_queue = Queue(maxsize=10)
+        self._refuse_mp()
+        self.infer_queue, self.track_queue, self.write_queue, self.final_queue = (Queue(maxsize=10) for _ in range(4))
+
+    def _refuse_mp(self):
+        if self.args.op_proc == 'mp':
+            raise ValueError(self._MP_MESSAGE)
 
     def start(self):
-        if self.args.op_proc == 'mp':
-            raise ValueError("mp not supported for now, openpose inference seems to cause the mp to hang.")
+        self._refuse_mp()
         self.p_extract = Thread(target=self.extract_skeletons, args=())
         self.p_track = Thread(target=self.track, args=())
         self.p_write = Thread(target=self.writeout, args=())
-        for t in (self.p_extract, self.p_track, self.p_write):
-            t.start()
+        for worker in (self.p_extract, self.p_track, self.p_write):
+            worker.start()
 
     def queue_input(self, args):
         self.infer_queue.put(args)
@@ -166,69 +170,63 @@ class ExtractSkeletonAndTrack:
         self.queue_input((None, None, None, None, True))
         self.queue_output()
 
-    # stage 1: estimator ------------------------------------------------------------
+    @staticmethod
+    def _pump(inbox, outbox, out_width, stage):
+        while True:
+            *fields, stop = inbox.get()
+            if stop:
+                outbox.put((None,) * (out_width - 1) + (stop,))
+                return
+            outbox.put(tuple(stage(*fields)) + (stop,))
+
     def extract_skeletons(self):
-        while True:
-            color_filepath, depth_filepath, skel_filepath, intr_mat, break_loop = self.infer_queue.get()
-            if break_loop:
-                self.track_queue.put((None,) * 9 + (break_loop,))
-                break
-            infer_out = extract_2dskeletons(args=self.args, pose_extractor=self.PE, color_src=color_filepath,
-                                            depth_src=depth_filepath, intr_mat=intr_mat,
-                                            skeleton_folder=skel_filepath, enable_timer=self.enable_timer)
-            pyop = self.PE.pyop
-            if pyop.pose_empty:
-                boxes = scores = keypoints = heatmaps = filered_skel = None
-            else:  # copies: the estimator's buffers are overwritten by the next frame
-                boxes = pyop.pose_bounding_box.copy()
-                scores = pyop.pose_scores.copy()
-                keypoints = pyop.pose_keypoints.copy()
-                heatmaps = pyop.pose_heatmaps.copy()
-                filered_skel = pyop.filtered_skel
-            img = pyop.opencv_image.copy()
-            self.track_queue.put((img, boxes, scores, keypoints, heatmaps, filered_skel,
-                                  infer_out['data_prep_time'] + 1e-8, infer_out['infer_time'] + 1e-8,
-                                  color_filepath, break_loop))
+        self._pump(self.infer_queue, self.track_queue, 10, self._estimate)
 
-    # stage 2: tracker ---------------------------------------------------------------
     def track(self):
-        while True:
-            (img, boxes, scores, keypoints, heatmaps, filered_skel, prep_time, infer_time, color_fp,
-             break_loop) = self.track_queue.get()
-            if break_loop:
-                self.write_queue.put((None,) * 6 + (break_loop,))
-                break
-            if boxes is not None and self.TK is not None:
-                with Timer("update", self.enable_timer, False) as t:
-                    image_size = (self.args.op_image_width, self.args.op_image_height)
-                    self.TK.update(boxes, scores, keypoints, heatmaps, image_size)
-                if self.args.op_save_track_image:
-                    img = PYOP._draw_text_on_skeleton_image(img, scores)
-                    img = PYOP._draw_tracking_bounding_box_image(img, self.TK.tracks)
-                duration = t.duration + 1e-8
-            else:
-                if self.TK is not None:
-                    self.TK.no_measurement_predict_and_update()
-                if self.args.op_save_track_image:
-                    img = PYOP._draw_text_on_skeleton_image(img, scores)
-                    img = PYOP._draw_bounding_box_on_skeleton_image(img, boxes)
-                duration = -1
-            self.write_queue.put((img, filered_skel, prep_time, infer_time, duration, color_fp, break_loop))
+        self._pump(self.track_queue, self.write_queue, 7, self._associate)
 
-    # stage 3: writer ------------------------------------------------------------------
     def writeout(self):
-        while True:
-            img, filered_skel, prep_time, infer_time, track_time, color_fp, break_loop = self.write_queue.get()
-            if break_loop:
-                self.final_queue.put((None, None, None, None, break_loop))
-                break
-            if self.args.op_save_track_image and filered_skel is not None:
-                parts = color_fp.split('/')
-                name = getattr(self.TK, 'name', 'notracker')
-                save_file = color_fp.replace(parts[-2], f'{parts[-2]}_{name}')
-                os.makedirs(os.path.dirname(save_file), exist_ok=True)
-                _write_image(save_file, img)
-            self.final_queue.put((filered_skel, prep_time, infer_time, track_time, break_loop))
+        self._pump(self.write_queue, self.final_queue, 5, self._store)
+
+    # stage 1: (color, depth, skeleton folder, intrinsics) ->
+    #          (image, boxes, scores, keypoints, heatmaps, filtered_skel, prep s, infer s, color)
+    def _estimate(self, color, depth, skeleton_folder, intr_mat):
+        times = extract_2dskeletons(args=self.args, pose_extractor=self.PE, color_src=color, depth_src=depth,
+                                    intr_mat=intr_mat, skeleton_folder=skeleton_folder,
+                                    enable_timer=self.enable_timer)
+        pyop = self.PE.pyop
+        # copies: the estimator overwrites its buffers with the next frame while the tracker thread reads these
+        found = [None] * 5 if pyop.pose_empty else \
+            [np.copy(pyop.pose_bounding_box), np.copy(pyop.pose_scores), np.copy(pyop.pose_keypoints),
+             np.copy(pyop.pose_heatmaps), pyop.filtered_skel]
+        return (np.copy(pyop.opencv_image), *found, times['data_prep_time'] + 1e-8, times['infer_time'] + 1e-8, color)
+
+    # stage 2: -> (image, filtered_skel, prep s, infer s, track s | -1, color)
+    def _associate(self, image, boxes, scores, keypoints, heatmaps, filtered_skel, prep_s, infer_s, color):
+        annotate = self.args.op_save_track_image
+        if boxes is None or self.TK is None:  # nobody in the frame (or no tracker): the tracks only age
+            if self.TK is not None:
+                self.TK.no_measurement_predict_and_update()
+            track_s = -1
+            if annotate:
+                image = PYOP._draw_bounding_box_on_skeleton_image(PYOP._draw_text_on_skeleton_image(image, scores), boxes)
+        else:
+            with Timer("update", self.enable_timer, False) as clock:
+                self.TK.update(boxes, scores, keypoints, heatmaps, (self.args.op_image_width, self.args.op_image_height))
+            track_s = clock.duration + 1e-8
+            if annotate:
+                image = PYOP._draw_tracking_bounding_box_image(PYOP._draw_text_on_skeleton_image(image, scores),
+                                                               self.TK.tracks)
+        return image, filtered_skel, prep_s, infer_s, track_s, color
+
+    # stage 3: -> (filtered_skel, prep s, infer s, track s); writes <root>/<sensor>_<tracker name>/<file>
+    def _store(self, image, filtered_skel, prep_s, infer_s, track_s, color):
+        if self.args.op_save_track_image and filtered_skel is not None:
+            sensor = color.split('/')[-2]
+            target = color.replace(sensor, f"{sensor}_{getattr(self.TK, 'name', 'notracker')}")
+            os.makedirs(os.path.dirname(target), exist_ok=True)
+            _write_image(target, image)
+        return filtered_skel, prep_s, infer_s, track_s
 
 
 def _sorted_files(base_path: str) -> List[str]:
@@ -383,7 +381,7 @@ def extract_2dskeletons_and_track_offline(args: argparse.Namespace, tracker=None
         else:
             delay_counter = delay_switch
             EST.queue_input((color_filepath, None, _skeleton_folder(color_filepath), None, False))
-            filered_skel, prep_time, infer_time, track_time, _ = EST.queue_output()
+            kept_total, prep_time, infer_time, track_time, _ = EST.queue_output()
             status = EST.PE.display(win_name='000', speed=1, scale=args.op_display, image=None,
                                     bounding_box=False, tracks=EST.TK.tracks)
             if not status[0]:
@@ -391,7 +389,7 @@ def extract_2dskeletons_and_track_offline(args: argparse.Namespace, tracker=None
             runtime['PE'].append(1 / infer_time)
             runtime['TK'].append(1 / track_time)
             bar.set_description(f"Image : {color_filepath.split('/')[-1]} | "
-                                f"#Skel filtered : {filered_skel} | "
+                                f"#Skel filtered : {kept_total} | "
                                 f"#Tracks : {len(EST.TK.tracks)} | "
                                 f"Prep time : {prep_time:.3f} | "
                                 f"Pose time : {infer_time:.3f} | "

@@ -411,7 +411,8 @@ def test_reference_timing_harnesses_run_through_the_estimator_classes(tmp_path, 
                                                         net_resolution="-1x64", random_weights=0, save=True)
     text = capsys.readouterr().out
     assert "Average inference time over 3 trials" in text and "fps" in text
-    assert per_frame > 0 and fps > 0 and "/" in pyop.filtered_skel or pyop.pose_empty
+    assert per_frame > 0 and fps > 0
+    assert pyop.pose_empty or "/" in pyop.filtered_skel
     assert os.path.exists(tmp_path / "nat" / "predictions.txt")
     pyop.opWrapper.close()
 

@@ -42,6 +42,7 @@ def _check(got, ref):
     (46, 82, 656, 368, 5),
     (46, 82, 641, 359, 2),      # non-integer, anisotropic scale
     (46, 82, 1920, 1080, 3),    # BASELINE config 3: MOT17 1080p
+    (46, 82, 1920, 1080, 20),   # ... crowded, at the reference's default conf_thres = 0.1 (265 keypoints, 34 rows)
     (46, 82, 300, 200, 0),      # empty scene: every limb "No Connection"
 ])
 def test_decode_v1_matches_oracle(engine, hs, ws, W, H, people):

@@ -78,7 +78,8 @@ def test_run_inference_round_trip():
 
 def test_multipose_decode_matches_specification():
     rng = np.random.default_rng(21)
-    for B, G, P in ((3, 64, 6), (2, 16, 4), (1, 9, 12)):
+    # (64, 64, 6) = BASELINE configs[3]: batch 64 of the 256x256 MultiPose head (64x64 grid, 6 people)
+    for B, G, P in ((3, 64, 6), (64, 64, 6), (2, 16, 4), (1, 9, 12)):
         center = rng.uniform(0, 1, (B, G, G)).astype(np.float32) ** 4
         center[0, 0, 0] = center[0, G - 1, G - 1] = 1.0        # maxima on the border / corners
         heat = rng.uniform(0, 1, (B, G, G, 17)).astype(np.float32)
