@@ -5,9 +5,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 One process per GPU (the driver launches N>1 through torch.distributed.run);
-frames shard independently across ranks, no collective in the compute path,
-one RCCL all_gather of the packed, padded keypoint records per step.  A step
-is one batch of 32 synthetic frames per GPU, already resident in HBM:
+frames shard independently across ranks, no collective in the compute path;
+at N > 1 one RCCL gather (dst = rank 0) of the packed, padded keypoint record
+per step, at N = 1 no collective at all.  A step is one batch of 32 synthetic
+frames per GPU, already resident in HBM:
   u8 frames -> ph_preprocess -> ph_forward (MFMA implicit-GEMM convs) ->
   ph_decode_v2 (upsample+NMS, PAF matching, assembly) -> keypoints to host.
 Weights are He-normal random (no model files exist offline): same graph, same
@@ -54,30 +55,39 @@ def cpu_baseline(net, weights, model, n_frames, seed):
                       f"(oracle/net_ref.py + oracle/decode_v2.py); cv2.dnn/pyopenpose unavailable"}
 
 
+VALU_LANE_OPS_PER_S = 256 * 64 * 2.4e9    # 256 CUs x 64 lanes x 2.4 GHz: one fp32 VALU operation per lane and clock
+NMS_OPS_PER_PIXEL = 33                    # cubic in d (8) + column max / 3x3 test / threshold / bookkeeping
+
+
 def tail_block(B, src_h, src_w, pre_ms, decode_ms, paf_pairs):
-    """HBM-side view of the memory-bound tail (north star: achieved GB/s of resize / NMS / PAF against the
-    MI355X peak), per launch of B frames.  Bytes are ALGORITHMIC, durations are HIP events of this run:
-      preprocess  read H0*W0*3 u8 + write Hn*Wn*3 bf16 per frame
-      upsample+NMS  what upstream's resizeAndMerge -> nms moves: read 78 net-output planes, write 78 upsampled maps,
-                  read the 25 part maps back (100.6 MB/frame); the fused kernels read 25 planes once (`fused_bytes`)
-      PAF scoring  pairs x <=25 samples x 2 channels x 4 B gathered (pairs counted on this run's peaks)
-    A fraction above 1 only says the materialised traffic of the unfused algorithm never happens here."""
+    """The tail beside the convs, per launch of B frames; durations are HIP events of this run.
+      preprocess    HBM-bound: read H0*W0*3 u8 + write Hn*Wn*3 bf16 per frame (the buffer pads to 8 channels)
+      upsample+NMS  VALU-bound: the fused kernel reads 25 source planes once (`hbm_bytes`) and evaluates the bicubic
+                    + 3x3 test for every upsampled pixel in registers: NMS_OPS_PER_PIXEL fp32 operations per pixel
+                    against the chip's fp32 issue rate.  `unfused_algorithmic_bytes` is what upstream's
+                    resizeAndMerge -> nms moves (100.6 MB/frame) -- context, never a roofline fraction.
+      PAF scoring   VALU + LDS gather: pairs x <=25 samples x 2 channels x 4 B gathered from LDS-resident planes
+      assembly      latency-bound (a block per frame)"""
     hbm = 8000.0
     hs, ws = NET_H // 8, NET_W // 8
-    rows = {
-        "preprocess_kernel": (B * (src_h * src_w * 3 + NET_H * NET_W * 3 * 2), None, pre_ms),
-        "nms_detect_cols_kernel+nms_refine_kernel": (B * (78 * hs * ws * 4 + 78 * NET_H * NET_W * 4 + 25 * NET_H * NET_W * 4),
-                                                      B * 25 * hs * ws * 4, float(decode_ms[0])),
-        "paf_score_kernel": (paf_pairs * 25 * 2 * 4, None, float(decode_ms[1])),
-    }
     out = {}
-    for k, (alg, fused, ms) in rows.items():
-        gbs = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        out[k] = {"algorithmic_bytes": int(alg), "us": round(ms * 1e3, 1), "GB_per_s": round(gbs, 1),
-                  "frac_of_8TBps": round(gbs / hbm, 4)}
-        if fused is not None:
-            out[k]["fused_bytes"] = int(fused)
-    out["assemble_merge_kernel"] = {"us": round(float(decode_ms[2]) * 1e3, 1), "bound": "latency (one block per frame)"}
+    pre_bytes = B * (src_h * src_w * 3 + NET_H * NET_W * 3 * 2)
+    gbs = pre_bytes / (pre_ms * 1e-3) / 1e9 if pre_ms > 0 else 0.0
+    out["preprocess_kernel"] = {"bound": "hbm", "algorithmic_bytes": int(pre_bytes), "us": round(pre_ms * 1e3, 1),
+                                "GB_per_s": round(gbs, 1), "frac_of_8TBps": round(gbs / hbm, 4)}
+    nms_ms = float(decode_ms[0])
+    ops = B * 25 * NET_H * NET_W * NMS_OPS_PER_PIXEL
+    rate = ops / (nms_ms * 1e-3) if nms_ms > 0 else 0.0
+    out["nms_detect_cols_kernel+nms_refine_kernel"] = {
+        "bound": "valu", "us": round(nms_ms * 1e3, 1), "upsampled_pixels": B * 25 * NET_H * NET_W,
+        "ops_per_pixel": NMS_OPS_PER_PIXEL, "achieved_Tops_per_s": round(rate / 1e12, 2),
+        "peak_Tops_per_s": round(VALU_LANE_OPS_PER_S / 1e12, 2), "frac_of_fp32_issue_rate": round(rate / VALU_LANE_OPS_PER_S, 4),
+        "hbm_bytes": int(B * 25 * hs * ws * 4),
+        "unfused_algorithmic_bytes": int(B * (78 * hs * ws * 4 + 78 * NET_H * NET_W * 4 + 25 * NET_H * NET_W * 4))}
+    paf_ms = float(decode_ms[1])
+    out["paf_score_kernel"] = {"bound": "valu+lds", "us": round(paf_ms * 1e3, 1), "candidate_pairs": int(paf_pairs),
+                               "gathered_bytes": int(paf_pairs * 25 * 2 * 4)}
+    out["assemble_merge_kernel"] = {"bound": "latency", "us": round(float(decode_ms[2]) * 1e3, 1)}
     return out
 
 
@@ -182,7 +192,26 @@ def main():
             d["gbins"] = [torch.empty((d["pack"].numel(),), dtype=torch.float32, device=gdev)
                           for _ in range(world)] if rank == 0 else None
             d["hpack"] = torch.empty((d["pack"].numel(),), dtype=torch.float32).pin_memory()
-    cur = torch.cuda.current_stream()
+    # Frames that arrive in HOST memory (a video stream: BASELINE configs[4]) are brought in by a dedicated copy
+    # stream, one batch ahead: every engine owns two device frame buffers, the copy of its NEXT batch is issued right
+    # after this batch's preprocess has been enqueued and is handed over by an event, so no copy sits on the critical
+    # path of an engine's stream and no host-side wait is needed for it.
+    copy_stream = torch.cuda.Stream(device=dev)
+    for d in bufs:
+        d["fr"] = [d["frames"], None]
+        d["copied"] = [torch.cuda.Event(), torch.cuda.Event()]
+        d["pre_done"] = [None, None]
+        d["cnt"], d["prefetched"] = 0, False
+
+    def issue_copy(d, j):
+        if d["fr"][j] is None:
+            d["fr"][j] = torch.empty_like(d["frames"])
+        with torch.cuda.stream(copy_stream):
+            if d["pre_done"][j] is not None:       # the preprocess that last read this buffer (two batches ago)
+                copy_stream.wait_event(d["pre_done"][j])
+            d["fr"][j].copy_(frames_host, non_blocking=True)
+            d["copied"][j].record(copy_stream)
+
     trace = (lambda *a: print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)) if os.environ.get("BENCH_TRACE") \
         else (lambda *a: None)
     trace("engines built")
@@ -195,9 +224,19 @@ def main():
         if i >= S and not os.environ.get("BENCH_DIAG_NO_DECODE"):
             e.decode_v2_status()   # raises if that batch's decode dropped people (person table overflow)
         if args.h2d:
-            with torch.cuda.stream(ts):
-                d["frames"].copy_(frames_host, non_blocking=True)
-        e.preprocess(d["frames"], _ffi.PH_PRE_NATIVE)
+            j = d["cnt"] % 2
+            if not d["prefetched"]:
+                issue_copy(d, j)
+            ts.wait_event(d["copied"][j])
+            e.preprocess(d["fr"][j], _ffi.PH_PRE_NATIVE)
+            if d["pre_done"][j] is None:
+                d["pre_done"][j] = torch.cuda.Event()
+            d["pre_done"][j].record(ts)
+            d["cnt"] += 1
+            issue_copy(d, d["cnt"] % 2)            # this engine's next batch, S steps ahead of its use
+            d["prefetched"] = True
+        else:
+            e.preprocess(d["frames"], _ffi.PH_PRE_NATIVE)
         e.forward(B)
         if not os.environ.get("BENCH_DIAG_NO_DECODE"):   # diagnostic only: what the decode costs end to end
             e.decode_v2_dev(BODY_25, B, NET_H, NET_W, kp_scale, MAX_PEOPLE)
@@ -229,16 +268,24 @@ def main():
         for i in range(n_steps):
             step(i)
         torch.cuda.synchronize()
+        el_own[0] = time.perf_counter() - t0
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
         if world > 1:
+            # every rank's own time for the K steps (taken before the closing barrier would hide it)
+            t = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            t[rank] = el_own[0]
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            rank_seconds[:] = [float(v) for v in t.tolist()]
             t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
 
+    el_own, rank_seconds = [0.0], []
     dt = timed(args.warmup, args.steps)
+    rank_seconds_headline = list(rank_seconds)
     trace("timed region done", dt)
     # what rank 0 gathered for its own shard must be what it decoded (the last step of every engine in flight)
     gather_checked = None
@@ -304,13 +351,12 @@ def main():
         print(f"total {ms.sum():.3f} ms, conv {ms[conv_mask].sum():.3f} ms", file=sys.stderr)
 
     if rank == 0:
-        try:  # opportunistic real-engine check, never a dependency
-            import cv2  # noqa: F401
-            has_cv2 = True
-        except Exception:
-            has_cv2 = False
-        mdir = os.environ.get("POSEHIP_MODEL_DIR", "")
-        if not (has_cv2 and mdir and os.path.isdir(mdir)):
+        # opportunistic real-engine check (cv2.dnn on the COCO model against posehip, same images), never
+        # a dependency: None when cv2, $POSEHIP_MODEL_DIR or $POSEHIP_SAMPLE_GLOB's images are absent
+        from posehip import real_engine
+        real = real_engine.run(os.environ.get("POSEHIP_MODEL_DIR", ""),
+                               os.environ.get("POSEHIP_SAMPLE_GLOB", os.path.join(ROOT, "data", "sample", "*.jpg")))
+        if real is None:
             print("real-engine parity: not available on this host (cv2 / Caffe model files absent)", file=sys.stderr)
         fps = world * B * args.steps / dt
         conv_s = conv_ms_total / 1e3
@@ -331,8 +377,9 @@ def main():
         d_ms, d_fl, d_n = by_k[dom]
         d_ach = d_fl / (d_ms / 1e3) / 1e12 if d_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-        if os.path.exists(tpath):  # PMC passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE) of this same command
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic.json") for r in (3, 2))
+                      if os.path.exists(q)), "")
+        if tpath:  # PMC passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE) of this same command
             with open(tpath) as fh:
                 traffic = json.load(fh).get("bytes_per_launch", {}).get(dom)
         line = {
@@ -347,8 +394,8 @@ def main():
                        "batch_per_gpu": B, "net_resolution": f"{NET_W}x{NET_H}", "source_frames": f"{src_w}x{src_h}", "weights": "random He-normal",
                        "frames": "pinned host, H2D every step" if args.h2d else "resident in HBM",
                        "batches_in_flight_per_gpu": S,
-                       "parallelism": f"frame-parallel x{world}, one RCCL gather of the packed keypoint record to "
-                                      "rank 0 per step"},
+                       "parallelism": (f"frame-parallel x{world}, one RCCL gather of the packed keypoint record to "
+                                       "rank 0 per step") if gather else "single GPU, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(d_ach, 2), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(d_ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": dom,
@@ -363,7 +410,7 @@ def main():
                                       "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
                                       "per_kernel_ms_per_step": {k: round(v[0] / n_prof, 3)
                                                                  for k, v in sorted(by_k.items())}},
-                         "traffic_source": "profiles/r02_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE of rocprofv3 PMC "
+                         "traffic_source": f"profiles/{os.path.basename(tpath)}: FETCH_SIZE x2 + WRITE_SIZE of rocprofv3 PMC "
                                            "passes of this command on the profiling box (not measured in this run)",
                          "decode_ms_per_step": [round(float(x) / n_prof, 3) for x in decode_ms],
                          "tail": tail_block(B, src_h, src_w, pre_ms / n_prof, decode_ms / n_prof, paf_pairs),
@@ -374,9 +421,11 @@ def main():
         if dt_h2d is not None:
             line["h2d_inclusive"] = {"value": round(world * B * args.steps / dt_h2d, 2), "unit": "frames/s",
                                      "ms_per_step": round(dt_h2d / args.steps * 1e3, 3),
+                                     "frac_of_resident": round(dt / dt_h2d, 4),
                                      "note": f"same {args.steps} steps with the u8 frames copied from pinned host "
                                              f"memory every step ({B * src_h * src_w * 3 / 1e6:.1f} MB/step over "
-                                             "PCIe); reported beside `value`, never as it"}
+                                             "PCIe) by a copy stream one batch ahead of the engines; reported "
+                                             "beside `value`, never as it"}
         if dt_sus is not None:
             line["sustained"] = {"value": round(world * B * args.sustained_steps / dt_sus, 2), "unit": "frames/s",
                                  "steps": args.sustained_steps,
@@ -384,6 +433,13 @@ def main():
                                  "note": "the same step run for about 2 s right after the timed region"}
         if gather_checked:
             line["config"]["gather_check"] = gather_checked
+        if real is not None:
+            line["real_engine"] = real
+        if world > 1 and rank_seconds_headline:
+            # stragglers: every rank's own frames/s over the K steps (the headline divides by the slowest)
+            per_rank = [B * args.steps / t for t in rank_seconds_headline]
+            line["per_rank"] = {"unit": "frames/s", "min": round(min(per_rank), 2), "max": round(max(per_rank), 2),
+                                "values": [round(v, 2) for v in per_rank]}
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(net, weights, BODY_25, args.cpu_frames, 1000)
         sys.stdout.flush()

@@ -83,7 +83,10 @@ typedef struct {
   int connector;      /* person assembly of upstream bodyPartConnector: 1 = what a CUDA build of OpenPose runs
                          (pafPtrIntoVector + pafVectorIntoPeopleVector: one score-sorted walk over all candidate
                          pairs with assign / extend / merge-if-disjoint) -- the reference's Docker image builds
-                         that; 0 = what a CPU-only build runs (per-limb sorted greedy + createPeopleVector) */
+                         that; 0 = what a CPU-only build runs (per-limb sorted greedy + createPeopleVector).
+                         Any other value is rejected (-1).  The struct has no spare fields: fill in EVERY member
+                         (a zero-initialised struct selects 0, the CPU-build route; posehip/tables.py's models and
+                         the ctypes binding default to 1) */
 } ph_v2_model;
 
 /* In-tree decode constants ("V1"; openpose/opencv/common.py MAPIDX :26-28 and
@@ -147,7 +150,8 @@ int ph_get_buffer(ph_ctx* ctx, int buf, uint16_t* host_out, int64_t n_elems);
  *      inside emplaceAndPop, native/python/skeleton.py:447) ------------------
  * Decodes the ctx's net output for B frames at target resolution Ht x Wt
  * (bicubic upsample never materialised).  Host outputs, caller-allocated:
- *   n_people   int32 [B]            people found (may exceed max_people)
+ *   n_people   int32 [B]            people stored per frame: those that pass the thresholds, at most max_people
+ *                                   (upstream stops at POSE_MAX_PEOPLE the same way)
  *   keypoints  f32   [B][max_people][n_parts][3]
  *   scores     f32   [B][max_people]
  *   peaks      f32   [B][n_parts][max_peaks+1][3]   (optional, may be NULL)

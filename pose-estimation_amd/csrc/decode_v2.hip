@@ -756,7 +756,8 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
     }
     if (total > 0) break;
   }
-  if (lane == 0) n_people[b] = total;
+  // (upstream's removePeopleBelowThresholds stops at POSE_MAX_PEOPLE: the count never exceeds the rows stored)
+  if (lane == 0) n_people[b] = total < max_people ? total : max_people;
 }
 
 // ---------------------------------------------------------------------------
@@ -1193,7 +1194,7 @@ __global__ __launch_bounds__(MRG_THREADS) void assemble_merge_kernel(
     }
     if (total > 0) break;
   }
-  if (tid == 0) n_people[b] = total;
+  if (tid == 0) n_people[b] = total < max_people ? total : max_people;   // as upstream: never more than the rows stored
   (void)s_total;
 }
 
@@ -1315,7 +1316,11 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   const int n_split = PH_V2_NMS_SPLIT;
   const int rows_per_split = (((Ht + n_split - 1) / n_split) + NMS_BAND - 1) / NMS_BAND * NMS_BAND;
   const int n_groups = (Wt - 1 + NMS_COLS - 1) / NMS_COLS;          // 62 output columns per wave and group
-  static const int nms_g_env = [] { const char* e = getenv("POSEHIP_NMS_G"); return e ? atoi(e) : 0; }();
+  static const int nms_g_env = [] {  // A/B override: only the instantiated widths 1, 2, 4 are taken, anything else is ignored
+    const char* e = getenv("POSEHIP_NMS_G");
+    const int v = e ? atoi(e) : 0;
+    return v == 1 || v == 2 || v == 4 ? v : 0;
+  }();
   // two columns per lane from 8 groups on: the two independent cubics pair up into packed fp32 operations
   // (0.29 vs 0.33 ms per 32 frames at 656 columns; four per lane is no faster).  POSEHIP_NMS_G overrides.
   const int nms_g = nms_g_env ? nms_g_env : (n_groups <= 7 ? 1 : (n_groups <= 32 ? 2 : 4));

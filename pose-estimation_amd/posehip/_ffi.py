@@ -155,7 +155,7 @@ def v2_model_struct(model):
     m.inter_threshold = model.inter_threshold
     m.inter_min_above_threshold = model.inter_min_above_threshold
     m.min_subset_score = model.min_subset_score
-    m.connector = int(getattr(model, "connector", 0))
+    m.connector = int(getattr(model, "connector", 1))   # tables.PoseModelV2's default: the CUDA build's route
     for k, (a, b) in enumerate(model.pairs):
         m.pairs[2 * k], m.pairs[2 * k + 1] = a, b
     for k, (a, b) in enumerate(model.mapidx):

@@ -250,6 +250,22 @@ def test_batch_pipeline_matches_sequential(engine):
             np.testing.assert_array_equal(gkp[b, :len(kp)], kp)
             np.testing.assert_array_equal(gsc[b, :len(sc)], sc)
     pipe.close()
+    # frames that arrive in host memory (pinned tensors and plain NumPy arrays): copy stream + two device frame
+    # buffers per engine; 9 submissions on 2 engines re-use every buffer at least twice
+    pipe = BatchPipeline(plan, B, BODY_25, h, w, device=0, depth=2)
+    order = [0, 1, 2, 3, 4, 2, 0, 4, 1]
+    host = [f.cpu().pin_memory() if i % 2 else f.cpu().numpy() for i, f in enumerate(batches)]
+    tickets = [pipe.submit_host(host[i]) for i in order]
+    for t, i in zip(tickets, order):
+        gn, gkp, gsc = pipe.result(t)
+        n, res = want[i]
+        np.testing.assert_array_equal(gn, n)
+        for b, (kp, sc) in enumerate(res):
+            np.testing.assert_array_equal(gkp[b, :len(kp)], kp)
+            np.testing.assert_array_equal(gsc[b, :len(sc)], sc)
+    with pytest.raises(ValueError):
+        pipe.submit_host(batches[0])              # a device tensor is not host memory
+    pipe.close()
 
 
 def test_three_engines_on_three_threads(engine):

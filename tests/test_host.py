@@ -268,3 +268,21 @@ def test_product_path_never_touches_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "pose-estimation_amd", "csrc")):
         for fn in files:
             assert "#include \"../../oracle" not in open(os.path.join(dirpath, fn)).read()
+
+
+def test_real_engine_comparison_function():
+    """posehip/real_engine.py: the array comparison the opportunistic cv2.dnn check reports (bench.py `real_engine`);
+    `run` itself needs cv2 + the Caffe model and returns None without them."""
+    from posehip import real_engine
+    ref = np.zeros((1, 3, 4, 5), np.float32)
+    got = ref.copy()
+    got[0, 1, 2, 3] = 0.004
+    ref_kp = np.array([[10, 10, 0.9], [50, 20, 0.8], [200, 100, 0.7]])
+    got_kp = np.array([[51, 20, 0.8], [10, 13, 0.9], [90, 90, 0.5]])
+    out = real_engine.compare(ref, got, ref_kp, got_kp)
+    assert abs(out["heatmap_max_abs_err"] - 0.004) < 1e-9
+    assert (out["keypoints_ref"], out["keypoints_got"], out["matched"]) == (3, 3, 2)
+    assert out["keypoint_max_px_err"] == 3.0
+    empty = real_engine.compare(ref, ref, np.zeros((0, 3)), np.zeros((0, 3)))
+    assert empty["matched"] == 0 and empty["keypoint_max_px_err"] is None and empty["heatmap_max_abs_err"] == 0.0
+    assert real_engine.run("/nonexistent", "/nonexistent/*.jpg") is None
