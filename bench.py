@@ -119,6 +119,13 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 by default): with three engine
+    # streams, the copy stream of the host-frame leg and the default stream, the copy stream shares a queue with an
+    # engine, and every 3.5 ms frame copy then holds up that engine's kernels (measured: 0.82 of the resident rate with
+    # 4 queues, 0.997 with 8; 0.999 with 4 queues and two engines).  One queue per stream, set before HIP comes up.
+    from posehip.pipeline import ensure_hw_queues
+    hw_queues = ensure_hw_queues(max(1, args.streams) + 2)
+
     import torch
     import torch.distributed as dist
     from posehip import _ffi, caffe_io, graph
@@ -393,7 +400,7 @@ def main():
                                    "(BASELINE configs[1])",
                        "batch_per_gpu": B, "net_resolution": f"{NET_W}x{NET_H}", "source_frames": f"{src_w}x{src_h}", "weights": "random He-normal",
                        "frames": "pinned host, H2D every step" if args.h2d else "resident in HBM",
-                       "batches_in_flight_per_gpu": S,
+                       "batches_in_flight_per_gpu": S, "hw_queues": hw_queues,
                        "parallelism": (f"frame-parallel x{world}, one RCCL gather of the packed keypoint record to "
                                        "rank 0 per step") if gather else "single GPU, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(d_ach, 2), "peak": MFMA_PEAK_TFLOPS,

@@ -286,3 +286,15 @@ def test_real_engine_comparison_function():
     empty = real_engine.compare(ref, ref, np.zeros((0, 3)), np.zeros((0, 3)))
     assert empty["matched"] == 0 and empty["keypoint_max_px_err"] is None and empty["heatmap_max_abs_err"] == 0.0
     assert real_engine.run("/nonexistent", "/nonexistent/*.jpg") is None
+
+
+def test_ensure_hw_queues_only_raises(monkeypatch):
+    """One hardware queue per stream for the host-frame pipeline (posehip/pipeline.py): the variable is raised to the
+    stream count, capped, and never lowered."""
+    from posehip.pipeline import ensure_hw_queues
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert ensure_hw_queues(3) == 4 and "GPU_MAX_HW_QUEUES" not in os.environ      # HIP's default already covers it
+    assert ensure_hw_queues(5) == 5 and os.environ["GPU_MAX_HW_QUEUES"] == "5"
+    assert ensure_hw_queues(40) == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"    # capped
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert ensure_hw_queues(5) == 16 and os.environ["GPU_MAX_HW_QUEUES"] == "16"   # never lowered
