@@ -31,6 +31,7 @@ int ph_launch_movenet_multipose(const float* center, const float* heat, const fl
                                 const float* boxs, int B, int G, int maxp, float min_center, int* c_idx,
                                 float* c_score, float* out, hipStream_t stream);
 int ph_conv_1x1_mw();
+bool ph_stem512_applies(const PhConvParams& p);
 int ph_launch_lift3d(const float* kp, const int* n_people, int B, int maxp, int J, const uint16_t* depth, int Hd,
                      int Wd, double fx, double fy, double cx, double cy, double depth_scale, int po, double* out,
                      hipStream_t stream);
@@ -90,6 +91,7 @@ struct Op {
   float* slope = nullptr;
   double flops = 0.0;  // algorithmic, per frame
   bool skip = false;   // computed inside the next op's kernel (stem fusion)
+  int* tile_ctr = nullptr;  // stem op: the persistent kernel's two tile counters
 };
 
 struct ph_ctx {
@@ -195,6 +197,7 @@ static void free_net(ph_ctx* c) {
     if (o.wt) (void)hipFree(o.wt);
     if (o.bias) (void)hipFree(o.bias);
     if (o.slope) (void)hipFree(o.slope);
+    if (o.tile_ctr) (void)hipFree(o.tile_ctr);
   }
   c->bufs.clear();
   c->ops.clear();
@@ -532,6 +535,10 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       q.in_coff = 0;
       q.NQ = batch * fb.Hp() * fb.Wp();
       if (q.Kpad0 < 96 || !ph_conv_halo_plan(q, 3, false)) continue;
+      PH_CHECK(hipMalloc(&b.tile_ctr, 2 * sizeof(int)));
+      PH_CHECK(hipMemset(b.tile_ctr, 0, 2 * sizeof(int)));
+      q.tile_ctr = b.tile_ctr;
+      q.tile_par = 0;
       b.cp = q;
       b.variant = 5;
       b.nrep = 2;  // the stem instantiation is 64 channels wide
@@ -595,6 +602,7 @@ static int run_ops(ph_ctx* c, int B, bool timed) {
       o.cp.M = B * o.cp.H * o.cp.W;
       if (o.variant >= 4) ph_conv_halo_plan(o.cp, o.d.kh, o.d.f32_coff >= 0);  // tile count follows B
       if (ph_launch_conv(o.cp, o.nrep, o.variant, c->stream)) return -1;
+      o.cp.tile_par ^= 1;
     }
   }
   if (timed) PH_CHECK(hipEventRecord(c->op_ev[c->ops.size()], c->stream));
@@ -638,6 +646,7 @@ int ph_op_kernel(ph_ctx* c, int op, char* name, int cap) {
   const Op& o = c->ops[op];
   if (o.skip) snprintf(name, cap, "(fused into the next op)");
   else if (o.d.type == PH_OP_POOL) snprintf(name, cap, "maxpool2x2_kernel");
+  else if (o.cp.stem && ph_stem512_applies(o.cp)) snprintf(name, cap, "conv_stem512_kernel(PhConvParams, int, int, int)");
   else if (o.cp.stem) snprintf(name, cap, "conv3x3_halo_kernel<2, 4, false, true, 9>");
   else if (o.variant == 6) snprintf(name, cap, "conv3x3_halo_kernel<%d, %d, false, false, 1>", o.nrep, ph_conv_1x1_mw());
   else if (o.variant == 4 || o.variant == 5)

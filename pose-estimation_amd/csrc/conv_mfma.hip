@@ -1159,8 +1159,11 @@ static int launch_halo_sel(const PhConvParams& p, int mw, hipStream_t stream) {
 
 // variant 0: im2col-gather kernel (any odd kernel size / channel count).  variant 4 / 5: 3x3 halo-patch kernel with
 // 4 / 8 waves, 6: 1x1 through the same pipeline (geometry from ph_conv_halo_plan).
+bool ph_stem512_applies(const PhConvParams& p);          // conv_stem.hip: the persistent stem kernel
+int ph_launch_stem512(const PhConvParams& p, hipStream_t stream);
+
 int ph_launch_conv(const PhConvParams& p, int nrep, int variant, hipStream_t stream) {
-  if (p.stem) return launch_halo_stem(p, stream);
+  if (p.stem) return ph_stem512_applies(p) ? ph_launch_stem512(p, stream) : launch_halo_stem(p, stream);
   if (variant == 6) {  // 1x1 through the halo pipeline
     switch (nrep) {
       case 1: return launch_halo_1x1<1>(p, stream);

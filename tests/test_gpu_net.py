@@ -195,7 +195,7 @@ def test_body25_batch32_production_tiles_meet_the_oracle(engine):
     names = engine.op_kernels()
     assert names.count("conv3x3_halo_kernel<4, 4, false, false, 9>") == 70      # the dominant kernel of the bench
     assert names.count("conv3x3_halo_kernel<3, 4, false, false, 9>") == 30
-    assert names.count("conv3x3_halo_kernel<2, 4, false, true, 9>") == 1        # stem (conv1_1 + conv1_2 + pool)
+    assert names.count("conv_stem512_kernel(PhConvParams, int, int, int)") == 1  # stem (conv1_1 + conv1_2 + pool)
     frames = synth.synth_frames(77, B, H, W)
     engine.preprocess(frames, _ffi.PH_PRE_NATIVE)
     engine.forward(B)
@@ -213,6 +213,34 @@ def test_body25_batch32_production_tiles_meet_the_oracle(engine):
         engine.preprocess(frames[k:k + 1], _ffi.PH_PRE_NATIVE)
         engine.forward(1)
         np.testing.assert_array_equal(engine.net_out(1)[0], got[k])
+
+
+@pytest.mark.parametrize("H,W,B", [(64, 96, 3), (80, 112, 2), (368, 656, 2)])
+def test_persistent_stem_kernel_equals_the_halo_stem(engine, H, W, B, monkeypatch):
+    """conv_stem512_kernel (persistent, weights resident in LDS, 16x32 tiles, pool inside the wave) against the halo
+    kernel's stem form (POSEHIP_STEM_KERNEL=0): same accumulation order, so the pooled conv1_2 output and everything
+    after it are bit-equal -- on sizes that are multiples of the tile, ragged in both directions, and full size."""
+    from posehip import synth
+    net = caffe_io.parse_prototxt(caffe_io.body25_prototxt(H, W))
+    weights = graph.random_weights(net, seed=31)
+    plan = graph.build_plan(net, weights)
+    frames = synth.synth_frames(5, B, H, W)
+    outs, pooled = [], []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("POSEHIP_STEM_KERNEL", flag)
+        engine.build(plan, B)
+        names = engine.op_kernels()
+        assert ("conv_stem512_kernel(PhConvParams, int, int, int)" in names) == (flag == "1")
+        for _ in range(2):                      # twice: the tile counters alternate between launches
+            engine.preprocess(frames, _ffi.PH_PRE_NATIVE)
+            engine.forward(B)
+        outs.append(engine.net_out(B))
+        assert plan.ops[1].get("pool", 0) == 1
+        pooled.append(engine.get_buffer(plan.ops[1]["dst"][0][0]))       # pool1: what the stem kernel writes
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(pooled[0], pooled[1])
+    assert np.abs(pooled[1]).max() > 0
 
 
 def test_coco_full_size_forward_and_v1_decode(engine):
