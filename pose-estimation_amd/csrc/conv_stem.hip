@@ -134,10 +134,18 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
 
   const int tiles_per_image = tiles_x * tiles_y;
   bf16x8 xf[5][3];
+#pragma unroll
+  for (int u = 0; u < 5; u++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) xf[u][2][e] = (bf16)0.f;  // (lanes that never load K step 2 multiply zeros by zero weights)
+  int nx_b = 0, nx_y0 = 0, nx_x0 = 0;  // image and origin of the tile whose frame pixels were requested last
   auto issue_loads = [&](int t) {
     const int b = t / tiles_per_image;
     const int r2 = t - b * tiles_per_image;
     const int ty = r2 / tiles_x, tx = r2 - ty * tiles_x;
+    nx_b = b;
+    nx_y0 = ty * ST_TH;
+    nx_x0 = tx * ST_TW;
     // frame pixel under tap (0,0) of patch pixel (0,0): image (ty*16 - 2, tx*32 - 2)
     const int Q0 = (b * Hp + ty * ST_TH - 2 + pi) * Wp + tx * ST_TW - 2 + pi;
     int toff[3];
@@ -157,7 +165,8 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
       for (int ks = 0; ks < 3; ks++) {
         int Q = Q0 + rel + toff[ks];
         Q = Q < 0 ? 0 : (Q < p.NQ ? Q : p.NQ - 1);
-        xf[u][ks] = *(const bf16x8*)((const char*)p.in + (size_t)(unsigned)Q * 16u);
+        // K step 2 = taps 8..11, of which only tap 8 (the lanes with fq == 0) has weights: a quarter of the lanes load
+        if (ks < 2 || fq == 0) xf[u][ks] = *(const bf16x8*)((const char*)p.in + (size_t)(unsigned)Q * 16u);
       }
     }
   };
@@ -165,13 +174,17 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
   // pooled rows of the previous tile, stored one phase later (see P3)
   u32x4 pend[2];
   int pend_b = 0, pend_row = 0x7fffffff, pend_col0 = 0;
+  const PhDst ds0 = p.dst[0];  // (nearly always the only destination: kept in scalar registers)
   auto flush_rows = [&]() {
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int v = lane + 64 * q;
       const int pcol = pend_col0 + (v >> 3);
       if (pend_row < (p.H >> 1) && pcol < (p.W >> 1)) {
-        for (int d = 0; d < p.n_dst; d++) {
+        // (element offsets fit 31 bits: ph_stem512_applies checks the destination sizes)
+        const unsigned off0 = (unsigned)(((pend_b * ds0.Hp + pend_row) * ds0.Wp + pcol) * ds0.Cs + (v & 7) * 8 + ds0.org);
+        *(u32x4*)((char*)ds0.base + (size_t)off0 * 2u) = pend[q];
+        for (int d = 1; d < p.n_dst; d++) {
           const PhDst ds = p.dst[d];
           *(u32x4*)(ds.base + (size_t)ds.org + ((size_t)(pend_b * ds.Hp + pend_row) * ds.Wp + pcol) * ds.Cs + (v & 7) * 8) =
               pend[q];
@@ -185,17 +198,15 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
   __syncthreads();  // weights, biases and s_tn[0] are in LDS
   int it = 0;
   while (t < ntiles) {
-    const int tb = t / tiles_per_image;
-    const int tr2 = t - tb * tiles_per_image;
-    const int tyi = tr2 / tiles_x;
-    const int ty0 = tyi * ST_TH, tx0 = (tr2 - tyi * tiles_x) * ST_TW;
+    const int tb = nx_b, ty0 = nx_y0, tx0 = nx_x0;  // (computed when this tile's frame pixels were requested)
 
     ST_T(c0_);
 #ifdef ST_STAMP
-    long long su_[2] = {0, 0};
+    long long su_[4] = {0, 0, 0, 0};
 #endif
     // ---- P1: conv1_1 -> the 18 x 34 x 64 patch in LDS ---------------------------------------------------------
     {
+      const float relu0_floor = p.act0 ? 0.f : -__builtin_inff();
       f32x4 b0[4];
 #pragma unroll
       for (int nb = 0; nb < 4; nb++) b0[nb] = *(const f32x4*)(s_bias0 + nb * 16 + fq * 4);
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             float v = a0[nb][e] + b0[nb][e];
-            if (p.act0) v = v > 0.f ? v : 0.f;
+            v = fmaxf(v, relu0_floor);
             o[e] = (bf16)(inside ? v : 0.f);
           }
           *(bf16x4*)(lds + (nb >> 1) * ST_PLANE + (wofs ^ ((nb & 1) << 5))) = o;
@@ -235,8 +246,14 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
       }
     }
     flush_rows();  // the previous tile's pooled rows (none before the first tile: pend_row is out of range)
+#ifdef ST_STAMP
+    su_[2] = __builtin_readcyclecounter();
+#endif
     // ---- the next tile: its number came in during the previous tile, its frame pixels travel during this K loop
     const int tn = __builtin_amdgcn_readfirstlane(s_tn[it & 1]);
+#ifdef ST_STAMP
+    su_[3] = __builtin_readcyclecounter();
+#endif
     issue_loads(tn < ntiles ? tn : ntiles - 1);  // (past the last tile: a harmless repeat, no branch around 15 loads)
     int tnn = ntiles;
     if (tid == 0 && tn < ntiles) tnn = (int)gridDim.x + atomicAdd(ctr, 1);
@@ -354,7 +371,9 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
       atomicAdd(&st_dbg[5], 1ull);
       atomicAdd(&st_dbg[6], (unsigned long long)(su_[0] - c0_));   // P1: up to the end of row block 0 (waits for loads)
       atomicAdd(&st_dbg[7], (unsigned long long)(su_[1] - su_[0])); // P1: row blocks 1..4
-      atomicAdd(&st_dbg[8], (unsigned long long)(c1_ - su_[1]));    // next tile number, address arithmetic, 15 loads issued
+      atomicAdd(&st_dbg[8], (unsigned long long)(su_[2] - su_[1]));  // previous tile's rows stored
+      atomicAdd(&st_dbg[9], (unsigned long long)(su_[3] - su_[2]));  // next tile number from LDS
+      atomicAdd(&st_dbg[10], (unsigned long long)(c1_ - su_[3]));    // address arithmetic, 15 loads issued
     }
 #endif
     t = tn;
@@ -373,6 +392,7 @@ static bool stem512_enabled() {  // (read at every build / launch: the test swit
 bool ph_stem512_applies(const PhConvParams& p) {
   return stem512_enabled() && p.stem && p.pool && p.cout == 64 && p.cin_read == 64 && p.Kpad == 576 && p.Kpad0 >= 96 &&
          p.n_dst >= 1 && p.tile_ctr && !(p.H & 1) && !(p.W & 1) &&
+         (unsigned long long)p.B * p.dst[0].Hp * p.dst[0].Wp * p.dst[0].Cs < 0x3fffffffull &&
          (unsigned long long)p.NQ * 16ull < 0xffffffffull;
 }
 

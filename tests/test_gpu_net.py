@@ -166,7 +166,7 @@ def test_fused_pool_and_kernel_names(engine):
     assert [o.get("pool", 0) for o in plan.ops] == [0, 1, 0, 0]          # p1 folded into c2
     engine.build(plan, 1)
     names = engine.op_kernels()
-    assert names[0] == "(fused into the next op)" and "true, 9>" in names[1]   # c1 computed inside c2 (stem)
+    assert names[0] == "(fused into the next op)" and names[1].startswith("conv_stem512_kernel")   # c1 inside c2 (stem)
     assert names[3].endswith("1>") or names[3].startswith("conv_igemm_kernel")
     unfused = graph.build_plan(net, weights, fuse_pool=False)
     assert [o["type"] for o in unfused.ops].count(_ffi.PH_OP_POOL) == 1

@@ -31,5 +31,5 @@ tot = sum(cyc[i] for i in range(5))
 for i, k in enumerate(names):
     print(f"{k:48s} {cyc[i] / n:9.0f} cycles per tile  {100 * cyc[i] / tot:5.1f} %")
 print(f"{'sum':48s} {tot / n:9.0f}")
-for i, k in ((6, "P1: row block 0 (waits for the loads)"), (7, "P1: row blocks 1..4"), (8, "P1: next tile number + 15 loads issued")):
+for i, k in ((6, "P1: row block 0 (waits for the loads)"), (7, "P1: row blocks 1..4"), (8, "P1: previous rows stored"), (9, "P1: next tile number"), (10, "P1: 15 loads issued")):
     print(f"  {k:46s} {cyc[i] / n:9.0f}")
