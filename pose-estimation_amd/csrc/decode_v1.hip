@@ -263,6 +263,275 @@ __global__ __launch_bounds__(V1_RUN_THREADS) void v1_runs_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------
+// K-A, column-streaming form (round 3; the tiled form above stays behind POSEHIP_V1_RUNS=0 for A/B runs).
+// The tiled kernel evaluates every pixel of an active tile from scratch (4 source reads + 2 table reads for the
+// resize, then two 3-tap passes through LDS: ~130 VALU operations and ~20 LDS accesses per pixel, 83 % VALU /
+// 54 % LDS busy, 5.4 ms for 32 COCO frames at 1080p).  At these upscaling ratios (x8 ... x23) almost all of that
+// is redundant: the two horizontally interpolated source rows a pixel mixes are the same for every output row
+// between two source rows.  Here a WAVE owns a strip of 256 columns (lane l: columns l, l+64, l+128, l+192 -- the
+// layout the run scan wants) and walks down 16 rows (short walks: a wave's rows are one dependent chain, and the chip
+// hides that latency only with many waves):
+//   * per lane and column the horizontal interpolation of the two current source rows lives in registers and is
+//     redone only when the source row pair changes;
+//   * a row costs, per pixel: the vertical mix (2 mul + 1 add), the row pass (neighbouring columns = neighbouring
+//     lanes by DPP wave shifts, the word seams by one readlane), the column pass over three rows kept in registers,
+//     one compare: ~16 operations, no LDS;
+//   * image borders need no special case: the halo columns / rows are evaluated at their reflect-101 coordinates;
+//   * rows whose source rows stay below the threshold (over the strip's source columns) are skipped;
+//   * runs are found by the tiled kernel's ballot + segmented max-scan, only in rows that have mask bits, collected
+//     in a per-wave LDS list and written with one global atomicAdd per flush.
+// Same IEEE operations in the same order as the tiled form (and as oracle/decode_v1.py): the run set is identical.
+// grid (strips_x * ceil(H / 64), n_parts, B), block 256 = 4 waves = 4 consecutive 16-row chunks of one strip.
+// ---------------------------------------------------------------------------
+#define V1C_ROWS 16
+#define V1C_WAVES 4
+#define V1C_LIST 160
+// first position >= pos of the 256-bit row mask m[0..3] whose bit is set (clear = false) / clear (clear = true); 256 if none
+__device__ __forceinline__ int v1c_next_bit(const unsigned long long* m, int pos, bool clear) {
+  for (int k = pos >> 6; k < 4; k++) {
+    unsigned long long w = clear ? ~m[k] : m[k];
+    if (k == (pos >> 6)) w &= ~0ull << (pos & 63);
+    if (w) return 64 * k + __ffsll((long long)w) - 1;
+  }
+  return 256;
+}
+// maximum over each row of 16 lanes, in every lane of the row (quad swaps, then the two mirrors)
+__device__ __forceinline__ unsigned v1c_max16(unsigned x) {
+  unsigned o;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);
+  x = o > x ? o : x;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);
+  x = o > x ? o : x;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, true);
+  x = o > x ? o : x;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, true);
+  x = o > x ? o : x;
+  return x;
+}
+__global__ __launch_bounds__(64 * V1C_WAVES) void v1_runs_cols_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
+                                                                       int W, int H, float thr, int n_parts, int run_cap,
+                                                                       int src_cap, int* __restrict__ n_runs,
+                                                                       V1Run* __restrict__ runs, int* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) float s_src[];   // staged source sub-rectangle (src_cap floats)
+  constexpr int NR = V1C_ROWS * V1C_WAVES;                         // rows per block
+  __shared__ LinX s_ly[NR + 4];     // rows Y0 - 2 .. Y0 + NR + 1 (reflected, source rows relative to the sub-rectangle)
+  __shared__ int s_hot[NR + 4];     // 1: that row's source rows can reach the threshold on this strip
+  __shared__ float s_rowmax[256];
+  __shared__ float s_max[V1C_WAVES];
+  __shared__ V1Run s_list[V1C_WAVES][V1C_LIST];
+  const int strips_x = (W + V1_TILE_W - 1) / V1_TILE_W;
+  const int sx_ = blockIdx.x % strips_x, by = blockIdx.x / strips_x;
+  const int part = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x0 = sx_ * V1_TILE_W, Y0 = by * NR;
+  const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
+  // source cells the block can reach (1-px blur halo, both bilinear taps)
+  const int xa = x0 > 0 ? x0 - 1 : 0, xb = x0 + V1_TILE_W < W ? x0 + V1_TILE_W : W - 1;
+  const int ya_ = Y0 > 0 ? Y0 - 1 : 0, yb_ = Y0 + NR < H ? Y0 + NR : H - 1;
+  const int sxa = lin_x(xa, W, ws).s0, sxb = lin_x(xb, W, ws).s1;
+  const int sya = lin_y(ya_, H, hs).s0, syb = lin_y(yb_, H, hs).s1;
+  const int sw = sxb - sxa + 1, sh = syb - sya + 1;
+  if (sw * sh > src_cap) {   // (the host sizes the buffer for the worst block; never expected)
+    if (tid == 0) *overflow = 1;
+    return;
+  }
+  float lm = -INFINITY;
+  for (int i = tid; i < sw * sh; i += 64 * V1C_WAVES) {
+    const int yy = i / sw, xx = i - yy * sw;
+    const float v = plane[(sya + yy) * ws + sxa + xx];
+    s_src[i] = v;
+    lm = fmaxf(lm, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) lm = fmaxf(lm, __shfl_xor(lm, o));
+  if (l == 0) s_max[wave] = lm;
+  __syncthreads();
+  float blk_max = s_max[0];
+  for (int i = 1; i < V1C_WAVES; i++) blk_max = fmaxf(blk_max, s_max[i]);
+  // resize + blur are convex combinations up to a few ulps: nothing here can exceed thr
+  const bool prune = thr > 0.f;
+  if (prune && blk_max < thr * 0.999f) return;
+  for (int r = tid; r < sh; r += 64 * V1C_WAVES) {
+    float m = -INFINITY;
+    for (int c = 0; c < sw; c++) m = fmaxf(m, s_src[r * sw + c]);
+    s_rowmax[r] = m;
+  }
+  __syncthreads();
+  for (int i = tid; i < NR + 4; i += 64 * V1C_WAVES) {
+    const int r = Y0 - 2 + i;
+    LinX t;
+    t.s0 = t.s1 = 0;
+    t.a0 = t.a1 = 0.f;
+    int hot = 0;
+    if (r >= -1 && r <= H) {
+      t = lin_y(reflect101(r, H), H, hs);
+      t.s0 -= sya;
+      t.s1 -= sya;
+      // (rows Y0 - 2 and Y0 + NR + 1 only feed the flags; their source rows may lie outside the staged rectangle)
+      const bool staged = t.s0 >= 0 && t.s1 < sh;
+      hot = !prune || !staged || fmaxf(s_rowmax[staged ? t.s0 : 0], s_rowmax[staged ? t.s1 : 0]) >= thr * 0.999f;
+    }
+    s_ly[i] = t;
+    s_hot[i] = hot;
+  }
+  __syncthreads();
+  const int ya = Y0 + V1C_ROWS * wave;
+  const int yb = ya + V1C_ROWS < H ? ya + V1C_ROWS : H;
+  if (ya >= H) return;
+
+  // per-lane column tables: words 0..3 = columns x0 + 64 k + l, word 4 = the halo column of the end lanes
+  int cs0[5], cs1[5];
+  float ca0[5], ca1[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    int x = k < 4 ? x0 + 64 * k + l : (l == 63 ? x0 + V1_TILE_W : x0 - 1);
+    x = x > W ? W : x;
+    const LinX t = lin_x(reflect101(x, W), W, ws);
+    // columns past the strip's reach (x > xb + 1 only exist beyond the image) are clamped into the staged rectangle
+    cs0[k] = min(max(t.s0 - sxa, 0), sw - 1);
+    cs1[k] = min(max(t.s1 - sxa, 0), sw - 1);
+    ca0[k] = t.a0;
+    ca1[k] = t.a1;
+  }
+  float hA[5], hB[5];
+  int ida = -1, idb = -1;
+  // row pass of the resized row r (reflected at the image border) -> t[0..3]
+  auto row_t = [&](int r, float* t) {
+    const LinX cy = s_ly[r - (Y0 - 2)];
+    const int na = __builtin_amdgcn_readfirstlane(cy.s0), nb = __builtin_amdgcn_readfirstlane(cy.s1);
+    if (na != ida || nb != idb) {   // a new source row pair: horizontal interpolation of both rows
+      ida = na;
+      idb = nb;
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        hA[k] = s_src[ida * sw + cs0[k]] * ca0[k] + s_src[ida * sw + cs1[k]] * ca1[k];
+        hB[k] = s_src[idb * sw + cs0[k]] * ca0[k] + s_src[idb * sw + cs1[k]] * ca1[k];
+      }
+    }
+    float v[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = hA[k] * cy.a0 + hB[k] * cy.a1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      // left / right neighbour: the next lane; at the word seams lane 63 of the previous / lane 0 of the next word,
+      // at the strip's ends the halo column (held by the end lanes themselves)
+      const float lo = k == 0 ? v[4] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k - 1]), 63));
+      const float ro = k == 3 ? v[4] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k + 1]), 0));
+      const float lf = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lo), __float_as_int(v[k]), 0x138, 0xf, 0xf, false));
+      const float rt = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ro), __float_as_int(v[k]), 0x130, 0xf, 0xf, false));
+      t[k] = v[k] * 0.5f + (lf + rt) * 0.25f;
+    }
+  };
+  // bit i of ns: some row of y-1 .. y+1, y = ya + i, can reach the threshold (the row needs its s); a row needs its
+  // t when one of its three consumers needs its s
+  unsigned long long ns;
+  {
+    const int i = ya + l - (Y0 - 2);
+    ns = __ballot(l < V1C_ROWS && ya + l < yb && (s_hot[l < V1C_ROWS ? i - 1 : 0] | s_hot[l < V1C_ROWS ? i : 0] | s_hot[l < V1C_ROWS ? i + 1 : 0]) != 0);
+  }
+  const unsigned long long nt = ns | (ns << 1) | (ns >> 1);
+  auto need_s = [&](int y) { return ((ns >> (y - ya)) & 1ull) != 0; };
+  auto need_t = [&](int r) {
+    return r < ya ? (ns & 1ull) != 0 : (((nt >> (r - ya)) & 1ull) != 0);   // (r - ya <= V1C_ROWS < 64)
+  };
+
+  int* cnt = n_runs + (size_t)b * n_parts + part;
+  V1Run* out = runs + ((size_t)b * n_parts + part) * run_cap;
+  V1Run* list = s_list[wave];
+  int n_list = 0;
+  auto flush = [&]() {
+    if (n_list == 0) return;
+    __builtin_amdgcn_wave_barrier();   // (the list was written by other lanes of this wave)
+    int base = 0;
+    if (l == 0) base = atomicAdd(cnt, n_list);
+    base = __shfl(base, 0);
+    for (int i = l; i < n_list; i += 64) {
+      if (base + i < run_cap) out[base + i] = list[i];
+      else *overflow = 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    n_list = 0;
+  };
+
+  float tp[4] = {0.f, 0.f, 0.f, 0.f}, tc[4] = {0.f, 0.f, 0.f, 0.f}, tn[4] = {0.f, 0.f, 0.f, 0.f};
+  if (need_t(ya - 1)) row_t(ya - 1, tp);
+  if (need_t(ya)) row_t(ya, tc);
+  for (int y = ya; y < yb; y++) {
+    if (need_t(y + 1)) row_t(y + 1, tn);
+    if (need_s(y)) {
+      float v[4];
+      unsigned long long mw[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        v[k] = tc[k] * 0.5f + (tp[k] + tn[k]) * 0.25f;
+        mw[k] = __ballot(v[k] > thr && x0 + 64 * k + l < W);
+      }
+#ifdef V1C_NO_RUNS
+      n_list += (int)__popcll(mw[0] ^ mw[1] ^ mw[2] ^ mw[3]);
+      if (n_list == 0x7fffffff) *overflow = 1;
+      if (0) {
+#else
+      if (mw[0] | mw[1] | mw[2] | mw[3]) {
+#endif
+        // ---- runs of this row, one after the other (uniform loop: a row holds a few).  Mask values are positive
+        // floats, so their bit patterns order like the values: the run's maximum is an integer wave reduction
+        // (4 DPP steps inside the rows of 16 lanes + 4 readlanes), its first position the lowest set bit of the
+        // ballots of "equals the maximum" -- what a left-to-right walk with `>` finds.
+        int n_row = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned long long nxt = (mw[k] >> 1) | (k < 3 ? (mw[k + 1] & 1ull) << 63 : 0ull);
+          n_row += __popcll(mw[k] & ~nxt);
+        }
+        if (n_list + n_row > V1C_LIST) flush();
+        int pos = 0;
+        while (true) {
+          const int start = v1c_next_bit(mw, pos, false);
+          if (start >= 256) break;
+          const int stop = v1c_next_bit(mw, start, true);   // first pixel past the run
+          unsigned key = 0u;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int px = 64 * k + l;
+            const unsigned kk = (px >= start && px < stop) ? __float_as_uint(v[k]) : 0u;
+            key = kk > key ? kk : key;
+          }
+          key = v1c_max16(key);
+          const unsigned m01 = max((unsigned)__builtin_amdgcn_readlane((int)key, 0), (unsigned)__builtin_amdgcn_readlane((int)key, 16));
+          const unsigned m23 = max((unsigned)__builtin_amdgcn_readlane((int)key, 32), (unsigned)__builtin_amdgcn_readlane((int)key, 48));
+          const unsigned best = max(m01, m23);
+          int bx = 256;
+#pragma unroll
+          for (int k = 3; k >= 0; k--) {
+            const int px = 64 * k + l;
+            const unsigned long long eq = __ballot(px >= start && px < stop && __float_as_uint(v[k]) == best);
+            if (eq) bx = 64 * k + __ffsll((long long)eq) - 1;
+          }
+          if (l == 0) {
+            V1Run r;
+            r.y = y;
+            r.xs = x0 + start;
+            r.xe = x0 + stop - 1;
+            r.bx = x0 + bx;
+            r.best = __uint_as_float(best);
+            list[n_list] = r;
+          }
+          n_list++;
+          pos = stop;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      tp[k] = tc[k];
+      tc[k] = tn[k];
+    }
+  }
+#ifndef V1C_NO_RUNS
+  flush();
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // Literal getKeypoints for blobs that are not "simple" (utils.py:14-22 = cv2.findContours(RETR_TREE,
 // CHAIN_APPROX_SIMPLE) + cv2.fillConvexPoly + minMaxLoc; oracle: decode_v1.py blob_peaks / find_contours_tree /
 // fill_convex_poly, which state the OpenCV sources).
@@ -1089,6 +1358,10 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   const size_t ldsC = (size_t)2 * hs * ws * 4;
   const size_t ldsD = (size_t)c.person_cap * (m.n_parts + 1) * 8;
   const size_t lim = 160 * 1024 - 8192;  // static __shared__ tables sit beside the dynamic region
+  if (hs > 256) {
+    ph_set_error("decode_v1: net output height %d beyond the run kernel's 256 source rows", hs);
+    return -1;
+  }
   if (ldsA > lim || ldsB > lim || ldsC > lim || ldsD > lim) {
     ph_set_error("decode_v1: LDS budget exceeded (%zu/%zu/%zu/%zu B)", ldsA, ldsB, ldsC, ldsD);
     return -1;
@@ -1106,8 +1379,19 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   PH_CHECK(hipMemsetAsync(w.kps, 0, sz.kps, stream));
   const int tiles = ((W + V1_TILE_W - 1) / V1_TILE_W) * ((H + V1_TILE_H - 1) / V1_TILE_H);
   if (ev) PH_CHECK(hipEventRecord(ev[0], stream));
-  hipLaunchKernelGGL(v1_runs_kernel, dim3(tiles, m.n_parts, B), dim3(V1_RUN_THREADS), ldsA, stream, net_out, C, hs, ws, W, H, thr,
-                     m.n_parts, c.run_cap, w.n_runs, w.runs, w.overflow);
+  static const bool tiled_runs = [] { const char* e = getenv("POSEHIP_V1_RUNS"); return e && e[0] == '0'; }();
+  if (tiled_runs) {
+    hipLaunchKernelGGL(v1_runs_kernel, dim3(tiles, m.n_parts, B), dim3(V1_RUN_THREADS), ldsA, stream, net_out, C, hs, ws, W, H,
+                       thr, m.n_parts, c.run_cap, w.n_runs, w.runs, w.overflow);
+  } else {
+    const int blocks = ((W + V1_TILE_W - 1) / V1_TILE_W) * ((H + V1C_ROWS * V1C_WAVES - 1) / (V1C_ROWS * V1C_WAVES));
+    // staged source sub-rectangle of a block: the cells that 64 + 2 rows x 256 + 2 columns can touch
+    const size_t src_rows = (size_t)((V1C_ROWS * V1C_WAVES + 2) * (double)hs / H) + 4;
+    const size_t src_cols = (size_t)((V1_TILE_W + 2) * (double)ws / W) + 4;
+    const size_t ldsA2 = (src_rows < (size_t)hs ? src_rows : hs) * (src_cols < (size_t)ws ? src_cols : ws) * 4;
+    hipLaunchKernelGGL(v1_runs_cols_kernel, dim3(blocks, m.n_parts, B), dim3(64 * V1C_WAVES), ldsA2, stream,
+                       net_out, C, hs, ws, W, H, thr, m.n_parts, c.run_cap, (int)(ldsA2 / 4), w.n_runs, w.runs, w.overflow);
+  }
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(v1_blobs_kernel, dim3(m.n_parts, B), dim3(256), ldsB, stream, net_out, C, hs, ws, W, H, m.n_parts,
                      c.run_cap, c.kp_cap, V1_VERT_POOL(c.run_cap), (const int*)w.n_runs, (const V1Run*)w.runs, w.ws_best,
