@@ -556,6 +556,23 @@ struct V1Grid {
   int W, H;
 };
 
+#ifdef V1B_STAMP
+// Diagnostic build only (tools/v1_blobs_stamp.py): where v1_blobs_kernel spends its time.
+__device__ unsigned long long v1b_dbg[16];
+extern "C" int ph_debug_v1_blobs(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(v1b_dbg), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(v1b_dbg), 16 * sizeof(unsigned long long));
+}
+#define V1B_ADD(i, v) atomicAdd(&v1b_dbg[i], (unsigned long long)(v))
+#define V1B_NOW() __builtin_readcyclecounter()
+#else
+#define V1B_ADD(i, v)
+#define V1B_NOW() 0ll
+#endif
+
 // sorted position of the piece that holds pixel (x, y), -1 for a background / outside pixel
 __device__ __forceinline__ int v1_piece_at(const V1Grid& g, int x, int y) {
   if (x < 0 || y < 0 || x >= g.W || y >= g.H) return -1;
@@ -673,6 +690,7 @@ __device__ int v1_trace(const V1Grid& g, int x0, int y0, bool is_hole, unsigned 
   }
   verts.base = __shfl(verts.base, 0, 8);
   __threadfence_block();   // lane 0's vertices, read by the whole group from here on
+  if (r == 0) V1B_ADD(13, guard);
   return (guard < V1_TRACE_CAP && __shfl(ok, 0, 8)) ? n : -1;
 }
 
@@ -696,6 +714,8 @@ __device__ void v1_consider(V1Paint& p, int j, int y, int lo, int hi) {
     p.cur = k > p.cur ? k : p.cur;
     return;
   }
+  V1B_ADD(3, hi - lo + 1);
+  V1B_ADD(4, 1);
   for (int x = lo; x <= hi; x++) {
     const unsigned long long k = v1_key(v1_smooth_at(p.plane, p.hs, p.ws, p.g.W, p.g.H, x, y), x, y, p.g.W);
     p.cur = k > p.cur ? k : p.cur;
@@ -794,7 +814,9 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
     } while (++y <= ymax);
     if (my_y >= 0) v1_paint_span(p, my_y, my_x1, my_x2);
     p.cur = v1_gmax(p.cur);   // the outline's skip test starts from the whole fill's maximum
+    if (r == 0) V1B_ADD(14, ymax - ymin + 1);
   }
+  [[maybe_unused]] const long long to_ = V1B_NOW();
   // outline
   if (n == 1) {
     if (r == 0) v1_paint_span(p, v[0].y, v[0].x, v[0].x);
@@ -820,6 +842,7 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
     }
   }
   p.cur = v1_gmax(p.cur);
+  if (r == 0) V1B_ADD(15, V1B_NOW() - to_);
 }
 
 // ---------------------------------------------------------------------------
@@ -857,6 +880,8 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
                                                        int* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) int ismem[];
   const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const long long tb0_ = V1B_NOW();
+  (void)tb0_;
   int n = n_runs[(size_t)b * n_parts + part];
   n = n > run_cap ? run_cap : n;
   float* out = kps + ((size_t)b * n_parts + part) * kp_cap * 3;
@@ -1015,26 +1040,44 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   }
   __syncthreads();
   const int nirr = s_nirr;
+  [[maybe_unused]] const long long tw0_ = V1B_NOW();
+  if (tid == 0) {
+    V1B_ADD(7, tw0_ - tb0_);
+    V1B_ADD(5, nirr);
+    V1B_ADD(9, 1);
+    V1B_ADD(10, n);
+  }
   if (nirr) {
     const V1Grid g = {srun, rowoff, W, H};
     V1Paint pt = {g, bval, byrow, R, plane, hs, ws, 0ull};
     // blob k of the list -> thread (k % 4) * 64 + k / 4: spread over the four waves first
     V1Verts vv = {vpool, &s_vused, vert_cap, 0, 0};
     const int lane = tid & 63, r = tid & 7;
-    for (int k = tid >> 3; k < nirr; k += 32) {   // one group of 8 lanes per blob
+    // one group of 8 lanes per blob.  Groups of one wave that walk different blobs run one after the other (their
+    // control flow differs), so consecutive blobs go to different WAVES first: blob k -> wave k % 4, group k / 4 % 8
+    for (int k = ((tid >> 3) & 7) * 4 + (tid >> 6); k < nirr; k += 32) {
       const int i = irr[k], me = roots[i];
       const int fp = c_disc[i], y_first = fp / W, y_last = ld(&ymaxv[me]);
       int c = i, sx = fp - y_first * W, sy = y_first;   // the outer border starts at the blob's first raster pixel
       bool hole = false;
       for (;;) {
+        [[maybe_unused]] const long long ta_ = V1B_NOW();
         const int nv = v1_trace(g, sx, sy, hole, (unsigned short)(c + 1), vv, mark, lane);
         if (nv <= 0) {
           *overflow = 1;
           break;
         }
+        [[maybe_unused]] const long long tb_ = V1B_NOW();
         pt.cur = 0ull;
         v1_fill_paint(pt, vpool + vv.base, nv, lane);
         if (r == 0) c_key[c] = pt.cur;
+        [[maybe_unused]] const long long tc_ = V1B_NOW();
+        if (r == 0) {
+          V1B_ADD(0, tb_ - ta_);
+          V1B_ADD(1, tc_ - tb_);
+          V1B_ADD(6, 1);
+          V1B_ADD(11, nv);
+        }
         // next hole border: the blob's first run end in raster order, from here on, that no trace has right-marked
         // (lane k looks at the k-th row of each 8)
         int hx = -1, hy = -1;
@@ -1077,6 +1120,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
     }
     __syncthreads();
   }
+  if (tid == 0) V1B_ADD(8, V1B_NOW() - tw0_);
   const int nc = s_ncont < kp_cap ? s_ncont : kp_cap;
   if (nc > nr) {
     // parents of the outer borders (RETR_TREE): the border met last on the first pixel's row = the one that
@@ -1148,6 +1192,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
     out[rank * 3 + 2] = resize_at(plane, hs, ws, W, H, x, y);
   }
   if (tid == 0) *out_n = nc;
+  if (tid == 0) V1B_ADD(12, V1B_NOW() - tb0_);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic build only: where v1_blobs_kernel spends its cycles (COCO, 1920x1080, B frames of P people).
+
+    make -C pose-estimation_amd BUILD=build_stamp LIB=lib/libposehip_stamp.so EXTRA=-DV1B_STAMP
+    POSEHIP_LIB=pose-estimation_amd/lib/libposehip_stamp.so python tools/v1_blobs_stamp.py [P] [B]
+"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pose-estimation_amd"))
+import numpy as np
+from posehip import _ffi, synth
+from posehip.engine import Engine
+from posehip.tables import COCO_18, MAPIDX, get_body_parts_and_pose_pairs
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+eng = Engine(0)
+bp, pp = get_body_parts_and_pose_pairs("COCO")
+eng.set_net_out(np.stack([synth.synth_net_output(2000 * P + i, P, COCO_18, 46, 82) for i in range(B)]))
+L = _ffi.lib(); cyc = (ctypes.c_ulonglong * 16)()
+for _ in range(3):
+    eng.decode_v1(bp, pp, MAPIDX, B, 1920, 1080, 0.1, kp_cap=256, person_cap=1024)
+L.ph_debug_v1_blobs(cyc, 1)
+eng.decode_v1(bp, pp, MAPIDX, B, 1920, 1080, 0.1, kp_cap=256, person_cap=1024)
+L.ph_debug_v1_blobs(cyc, 0)
+print("kernel ms (runs, blobs, pairs+assemble):", [round(t, 3) for t in eng.decode_v1_times()])
+nb = max(1, cyc[9])
+print(f"blocks {cyc[9]}, runs per block {cyc[10] / nb:.0f}, irregular blobs per block {cyc[5] / nb:.1f}, "
+      f"contours walked per block {cyc[6] / nb:.1f}, vertices per contour {cyc[11] / max(1, cyc[6]):.0f}")
+print(f"per block: setup {cyc[7] / nb:.0f} cycles, walk phase {cyc[8] / nb:.0f}, whole kernel {cyc[12] / nb:.0f}")
+nc = max(1, cyc[6])
+print(f"per contour (one group of 8 lanes): trace {cyc[0] / nc:.0f} cycles, fill + outline {cyc[1] / nc:.0f}")
+print(f"pixel-by-pixel re-evaluation: {cyc[4]} spans, {cyc[3]} pixels ({cyc[3] / nb:.0f} per block)")
+print(f"trace steps per contour {cyc[13] / nc:.0f} ({cyc[0] / max(1, cyc[13]):.0f} cycles per step); fill rows per contour "
+      f"{cyc[14] / nc:.0f}; outline {cyc[15] / nc:.0f} cycles per contour")
