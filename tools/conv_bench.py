@@ -18,7 +18,8 @@ from posehip import _ffi, caffe_io, graph, synth  # noqa: E402
 from posehip.engine import Engine  # noqa: E402
 
 SHAPES = {  # name: (H, W, Cin, Cout, k)
-    "conv1_2": (368, 656, 64, 64, 3),
+    "stem": (368, 656, 64, 64, 3),      # conv1_1 + conv1_2 + pool as the network runs them (conv_stem512_kernel)
+    "conv1_2": (368, 656, 64, 64, 3),   # the same conv behind a 1x1 producer: plain 3x3 form, no stem fusion
     "conv2_2": (184, 328, 128, 128, 3),
     "conv3_2": (92, 164, 256, 256, 3),
     "conv4_2": (46, 82, 512, 512, 3),
@@ -43,9 +44,16 @@ def main():
     for name in args.shapes.split(","):
         H, W, cin, cout, k = SHAPES[name]
         txt = f'input: "image"\ninput_dim: 1\ninput_dim: 3\ninput_dim: {H}\ninput_dim: {W}\n'
-        txt += caffe_io._conv("c0", "image", cin, 1) + caffe_io._act("ReLU", "r0", "c0")
-        txt += caffe_io._conv("c1", "c0", cout, k) + caffe_io._act("ReLU", "r1", "c1")
-        txt += caffe_io._conv("out", "c1", 8, 1)
+        if name == "stem":
+            txt += caffe_io._conv("c0", "image", cin, 3) + caffe_io._act("ReLU", "r0", "c0")
+            txt += caffe_io._conv("c1", "c0", cout, k) + caffe_io._act("ReLU", "r1", "c1")
+            txt += ('layer { name: "p1" type: "Pooling" bottom: "c1" top: "p1" pooling_param { pool: MAX kernel_size: 2 '
+                    'stride: 2 } }\n')
+            txt += caffe_io._conv("out", "p1", 8, 1)
+        else:
+            txt += caffe_io._conv("c0", "image", cin, 1) + caffe_io._act("ReLU", "r0", "c0")
+            txt += caffe_io._conv("c1", "c0", cout, k) + caffe_io._act("ReLU", "r1", "c1")
+            txt += caffe_io._conv("out", "c1", 8, 1)
         net = caffe_io.parse_prototxt(txt)
         w = graph.random_weights(net, 0, out_gain=1.0)
         plan = graph.build_plan(net, w, tile_overrides={"c1": args.tile_n} if args.tile_n else None)
