@@ -452,7 +452,6 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       const char* ev = getenv("POSEHIP_CONV_DEBUG");
       const char* eo = getenv("POSEHIP_CONV_DEBUG_OP");
       p.debug = ev ? atoi(ev) : 0;
-      p.debug_epi = getenv("POSEHIP_STAMP_EPI") ? 1 : 0;
       if (eo && atoi(eo) != i) p.debug = 0;
     }
     p.act = d.act;

@@ -55,7 +55,6 @@ struct PhConvParams {
   unsigned magic_pr;
   unsigned magic_e1, magic_e2;   // epilogue row table: ceil(2^32/d) of its two divisors (image size, row length), 0 = divide
   int lin;    // halo_mode 0 at BN = 128: branch-free K loop (POSEHIP_NO_LIN=1 turns it off for A/B runs)
-  int debug_epi;  // -DPH_LIN_STAMP builds: stamp the epilogue instead of the K loop (POSEHIP_STAMP_EPI=1)
   int debug;  // timing experiments only (POSEHIP_CONV_DEBUG): 1 skip A loads, 2 skip B loads, 4 skip MFMA
 };
 

@@ -25,20 +25,10 @@
 #define BK 64
 #define NTHREADS 256
 
-// Timing experiments only (PhConvParams::debug & 8): per-phase cycle sums over all blocks.
+// Timing experiments only (PhConvParams::debug & 8, the DBG instantiations): per-phase cycle sums over all blocks.
+// (The in-kernel stamp / timeline builds of rounds 1-2, -DPH_LIN_STAMP and -DPH_TIMELINE, were taken out of this file
+// in round 3; their results are in DESIGN 4 / 8 and profiles/r01_conv_timeline.txt, their code in the history.)
 __device__ unsigned long long ph_conv_dbg[8];
-#ifdef PH_TIMELINE
-// Diagnostic build only (tools/conv_timeline.py): per block of the last branch-free 3x3 launch, the 100 MHz
-// s_memrealtime at kernel entry, K loop start, K loop end and after the last store has been issued, + the CU id.
-__device__ unsigned long long ph_conv_tl[4096 * 5];
-__device__ unsigned long long ph_conv_tlw[1024 * 8 * 8];   // per wave of the first 1024 blocks: epilogue stamps
-extern "C" int ph_debug_conv_timeline_waves(unsigned long long* out, int nblocks) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ph_conv_tlw), (size_t)nblocks * 64 * sizeof(unsigned long long));
-}
-extern "C" int ph_debug_conv_timeline(unsigned long long* out, int nblocks) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ph_conv_tl), (size_t)nblocks * 5 * sizeof(unsigned long long));
-}
-#endif
 extern "C" int ph_debug_conv_cycles(unsigned long long* out, int reset) {
   if (reset) {
     unsigned long long z[8] = {0};
@@ -350,14 +340,6 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
   const bool dbg_t = DBG && (p.debug & 8) != 0;
   long long t0 = 0, t1 = 0, t2 = 0, tw = 0;
   if (dbg_t) t0 = clock64();
-#ifdef PH_LIN_STAMP
-  const long long s0_ = __builtin_readcyclecounter();
-  long long sst_[4] = {0, 0, 0, 0};
-#endif
-#ifdef PH_TIMELINE
-  const unsigned long long tl0_ = __builtin_amdgcn_s_memrealtime();
-  unsigned long long tl1_ = 0, tl2_ = 0, tw_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
 
   const unsigned nblk = gridDim.x;
   const unsigned bid = blockIdx.x;
@@ -524,15 +506,8 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       t = t < 8 ? t : 8;  // taps 9..11 carry zero weights: read any finite pixel
       toff[ks] = ((t / 3) * 20 + (t % 3)) * 16;
     }
-#ifdef PH_LIN_STAMP
-    const long long sa_ = __builtin_readcyclecounter();
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#ifdef PH_LIN_STAMP
-    const long long sb_ = __builtin_readcyclecounter();
-    sst_[0] = sb_ - sa_;
-#endif
     prev_cnt = 0;  // everything issued so far has landed
     for (int rb = wave >> 2; rb < 21; rb += NW / 4) {
       const int j = rb * 16 + lf;
@@ -559,9 +534,6 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       if (j < 324) *(bf16x4*)(lds + (nb >> 1) * patch_bytes + j * 64 + slot * 16 + (lq & 1) * 8) = o;
     }
     // (the first K step's barrier makes the patch visible to every wave)
-#ifdef PH_LIN_STAMP
-    sst_[1] = __builtin_readcyclecounter() - sb_;
-#endif
   }
   if (dbg_t) t1 = clock64();
 
@@ -582,20 +554,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
 #pragma unroll 1
     for (int s = 0; s < 6; s++) {
       const int cc = s / 3, kh = s - cc * 3;
-#ifdef PH_LIN_STAMP
-      const long long sc_ = __builtin_readcyclecounter();
-#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef PH_LIN_STAMP
-      const long long sd_ = __builtin_readcyclecounter();
-#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-#ifdef PH_LIN_STAMP
-      const long long se_ = __builtin_readcyclecounter();
-      sst_[2] += sd_ - sc_;
-      sst_[3] += se_ - sd_;
-#endif
       if (s + 1 < 6) {
         const int c1 = (s + 1) / 3, k1 = (s + 1) - c1 * 3;
 #pragma unroll
@@ -625,13 +586,6 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
     const char* const bb0 = bring + b_rd;
     const int astep = SI * 64;  // row block i of a tap sits SI pixels further on (SI = 16 or 24: the swizzle bit, bit 2
                                 // of the pixel index, is the same for every i)
-#ifdef PH_TIMELINE
-    tl1_ = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef PH_LIN_STAMP
-    long long st[6] = {0, 0, 0, 0, 0, 0};
-    const long long m0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
-#endif
 #pragma unroll 1
     for (int cc = 0; cc < nchunks; cc++) {
       const char* patch = lds + (cc & 1) * patch_bytes;
@@ -641,19 +595,9 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       for (int t = 0; t < 9; t++) {
         // everything issued before the previous step has landed (previous step: NBW weight + 1 patch piece,
         // none of the latter in tap 8)
-#ifdef PH_LIN_STAMP
-        long long cm = __builtin_readcyclecounter();
-#endif
         PH_WAIT_VMCNT(NBW + (((t + 8) % 9) < NPC ? 1 : 0));
-#ifdef PH_LIN_STAMP
-        long long c0 = __builtin_readcyclecounter();
-        st[5] += c0 - cm;
-#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#ifdef PH_LIN_STAMP
-        long long c1 = __builtin_readcyclecounter();
-#endif
         const char* bb = bb0 + (t % 3) * B_STAGE;
         int pv = pjl;
         asm volatile("" : "+v"(pv));  // (keeps the 9 tap offsets out of registers the accumulators need)
@@ -669,45 +613,18 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         for (int j = 0; j < NREP; j++) bfr[j] = *(const bf16x8*)(bb + j * 1024);
 #pragma unroll
         for (int i = 0; i < IB; i++) af[i] = *(const bf16x8*)(ap + i * astep);
-#ifdef PH_LIN_STAMP
-        long long c2 = __builtin_readcyclecounter();
-#endif
         load_b(t2, c2n, (t + 2) % 3, true);
         if (t < NPC) load_a(t, cn, nbuf, true);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef PH_LIN_STAMP
-        long long c3 = __builtin_readcyclecounter();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        long long c4 = __builtin_readcyclecounter();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int i = 0; i < IB; i++)
 #pragma unroll
           for (int j = 0; j < NREP; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);  // (or the MFMAs sink below the next barrier and the fragments double up)
-#ifdef PH_LIN_STAMP
-        long long c5 = __builtin_readcyclecounter();
-        st[0] += c1 - c0; st[1] += c2 - c1; st[2] += c3 - c2; st[3] += c4 - c3; st[4] += c5 - c4;
-#endif
       }
     }
-#ifdef PH_TIMELINE
-    tw_[0] = __builtin_amdgcn_s_memrealtime();
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetches past the end of K
-#ifdef PH_TIMELINE
-    tl2_ = __builtin_amdgcn_s_memrealtime();
-    tw_[1] = tl2_;
-#endif
-#ifdef PH_LIN_STAMP
-    if (lane == 0 && wave == 1 && !p.debug_epi) {
-      for (int k = 0; k < 6; k++) atomicAdd(&ph_conv_dbg[k], (unsigned long long)st[k]);
-      atomicAdd(&ph_conv_dbg[6], (unsigned long long)(__builtin_amdgcn_s_memtime() - m0_));
-      atomicAdd(&ph_conv_dbg[7], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r0_));
-    }
-#endif
   }
   int bslot = 0;
   int pbuf = 0;  // patch buffer of chunk cc
@@ -816,9 +733,6 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
   }
   if (dbg_t) t2 = clock64();
-#ifdef PH_LIN_STAMP
-  const long long sk_ = __builtin_readcyclecounter();
-#endif
 
   // ---- epilogue --------------------------------------------------------------
   // acc[i][j][e]: pixel row (wm*IB*16 + i*16 + fr), channel (wn*BN/2 + j*16 + fq*4 + e)
@@ -837,16 +751,7 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         acc[i][j][e] = v;
       }
   }
-#ifdef PH_LIN_STAMP
-  const long long e1_ = __builtin_readcyclecounter();
-#endif
-#ifdef PH_TIMELINE
-  tw_[2] = __builtin_amdgcn_s_memrealtime();
-#endif
   __syncthreads();  // all fragment reads done, no LDS-DMA in flight (the last step waited for vmcnt(0))
-#ifdef PH_TIMELINE
-  tw_[3] = __builtin_amdgcn_s_memrealtime();
-#endif
   // per output row: {batch index or -1, y << 16 | x} (interior coordinates)
   int2* s_row = (int2*)(lds + HALO_BM * CROWB);  // behind the staged output tile (which may cover every other region)
   if (tid >= HALO_BM) {
@@ -889,13 +794,6 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
           if (cbase + j * 16 + e < nvalid) o[(size_t)(j * 16 + e) * hw] = acc[i][j][e];
     }
   }
-#ifdef PH_LIN_STAMP
-  const long long e2_ = __builtin_readcyclecounter();
-  long long e3_ = e2_;
-#endif
-#ifdef PH_TIMELINE
-  tw_[4] = __builtin_amdgcn_s_memrealtime();
-#endif
   if (p.n_dst > 0) {
     // the whole 256 x BN tile goes through LDS at once (bias/slope and the K-loop buffers are dead by now)
 #pragma unroll
@@ -908,12 +806,6 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
         *(bf16x4*)(lds + (wm * IB * 16 + i * 16 + fr) * CROWB + (cbase + j * 16) * 2) = o;
       }
     __syncthreads();
-#ifdef PH_LIN_STAMP
-    e3_ = __builtin_readcyclecounter();
-#endif
-#ifdef PH_TIMELINE
-    tw_[5] = __builtin_amdgcn_s_memrealtime();
-#endif
     if (p.pool) {
       // 2x2/2 max pool of the 16x16 tile -> 8 x 8 pooled pixels
       // (destination loop outside: its descriptor is read once, not once per row)
@@ -970,39 +862,6 @@ __global__ __launch_bounds__(128 * MW, MW) void conv3x3_halo_kernel(const PhConv
       }
     }
   }
-#ifdef PH_LIN_STAMP
-  if (LINC && LIN && lane == 0 && wave == 1) {  // epilogue parts of the LIN instantiation: slots 0..3 of a second read-out
-    const long long e4_ = __builtin_readcyclecounter();
-    if (p.debug_epi) {
-      atomicAdd(&ph_conv_dbg[0], (unsigned long long)(e1_ - sk_));   // bias + activation
-      atomicAdd(&ph_conv_dbg[1], (unsigned long long)(e2_ - e1_));   // barrier + row table (+ fp32 output)
-      atomicAdd(&ph_conv_dbg[2], (unsigned long long)(e3_ - e2_));   // staging + barrier
-      atomicAdd(&ph_conv_dbg[3], (unsigned long long)(e4_ - e3_));   // store loop
-      atomicAdd(&ph_conv_dbg[4], 1ull);
-    }
-  }
-  if (STEM && lane == 0 && wave == 1) {
-    const long long se2_ = __builtin_readcyclecounter();
-    for (int k = 0; k < 4; k++) atomicAdd(&ph_conv_dbg[k], (unsigned long long)sst_[k]);
-    atomicAdd(&ph_conv_dbg[7], 1ull);
-    atomicAdd(&ph_conv_dbg[4], (unsigned long long)(sk_ - s0_));   // start .. end of K loop
-    atomicAdd(&ph_conv_dbg[5], (unsigned long long)(se2_ - sk_));  // epilogue
-  }
-#endif
-#ifdef PH_TIMELINE
-  if (LINC && LIN && lane == 0 && wave == 0 && blockIdx.x < 4096) {
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    unsigned long long* o = ph_conv_tl + blockIdx.x * 5;
-    o[0] = tl0_; o[1] = tl1_; o[2] = tl2_; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = hwid;
-  }
-  if (LINC && LIN && lane == 0 && blockIdx.x < 1024) {
-    tw_[6] = __builtin_amdgcn_s_memrealtime();
-    tw_[7] = tl0_;
-    unsigned long long* o = ph_conv_tlw + (blockIdx.x * 8 + wave) * 8;
-    for (int k = 0; k < 8; k++) o[k] = tw_[k];
-  }
-#endif
   if (dbg_t) {
     __syncthreads();
     if (tid == 0) {

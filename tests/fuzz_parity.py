@@ -299,18 +299,47 @@ def movenet_case(eng, seed):
     return recipe + f" G={G} P={P} ok"
 
 
+def stem_case(eng, seed):
+    """Round 3: the persistent stem kernel (conv1_1 + conv1_2 + pool) against the halo kernel's stem form, bit for bit,
+    at random even sizes and batches (ragged tiles in both directions, single-tile images, several images per block)."""
+    from posehip import caffe_io, graph, _ffi
+    rng = np.random.default_rng(seed)
+    H, W, B = 2 * int(rng.integers(4, 120)), 2 * int(rng.integers(4, 180)), int(rng.integers(1, 4))
+    txt = f'input: "image"\ninput_dim: 1\ninput_dim: 3\ninput_dim: {H}\ninput_dim: {W}\n'
+    txt += caffe_io._conv("c11", "image", 64, 3) + caffe_io._act("ReLU", "r11", "c11")
+    txt += caffe_io._conv("c12", "c11", 64, 3) + caffe_io._act("ReLU" if rng.random() < 0.8 else "PReLU", "r12", "c12")
+    txt += 'layer { name: "p1" type: "Pooling" bottom: "c12" top: "p1" pooling_param { pool: MAX kernel_size: 2 stride: 2 } }\n'
+    txt += caffe_io._conv("out", "p1", 8, 1)
+    net = caffe_io.parse_prototxt(txt)
+    plan = graph.build_plan(net, graph.random_weights(net, seed, out_gain=1.0))
+    frames = synth.synth_frames(seed, B, H, W)
+    got = []
+    for flag in ("0", "1"):
+        os.environ["POSEHIP_STEM_KERNEL"] = flag
+        eng.build(plan, B)
+        assert (eng.op_kernels()[1].startswith("conv_stem512")) == (flag == "1"), eng.op_kernels()
+        for _ in range(2):
+            eng.preprocess(frames, _ffi.PH_PRE_NATIVE)
+            eng.forward(B)
+        got.append(eng.get_buffer(plan.ops[1]["dst"][0][0]))
+    os.environ.pop("POSEHIP_STEM_KERNEL", None)
+    recipe = f"STEM seed={seed} {H}x{W} B={B}"
+    assert np.array_equal(got[0], got[1]) and np.abs(got[1]).max() > 0, recipe
+    return recipe + " ok"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=8.0)
     ap.add_argument("--seed0", type=int, default=0)
-    ap.add_argument("--only", type=str, default="", help="comma list of V2,V1,PRE,NET,POST,MOVENET")
+    ap.add_argument("--only", type=str, default="", help="comma list of V2,V1,PRE,NET,POST,MOVENET,STEM")
     args = ap.parse_args()
     eng = Engine(0)
     t_end = time.time() + args.minutes * 60
-    n = {"V1": 0, "V2": 0, "PRE": 0, "NET": 0, "POST": 0, "MOVENET": 0}
+    n = {"V1": 0, "V2": 0, "PRE": 0, "NET": 0, "POST": 0, "MOVENET": 0, "STEM": 0}
     seed = args.seed0
     while time.time() < t_end:
-        cases = ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE"), (net_case, "NET"), (post_case, "POST"), (movenet_case, "MOVENET"))
+        cases = ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE"), (net_case, "NET"), (post_case, "POST"), (movenet_case, "MOVENET"), (stem_case, "STEM"))
         if args.only:
             cases = tuple(c for c in cases if c[1] in args.only.split(","))
         for fn, key in cases:
@@ -322,7 +351,7 @@ def main():
             n[key] += 1
             print(msg, flush=True)
         seed += 1
-    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, {n['NET']} network cases, {n['POST']} post-processing cases, {n['MOVENET']} MoveNet cases, seeds {args.seed0}..{seed - 1}", flush=True)
+    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, {n['NET']} network cases, {n['POST']} post-processing cases, {n['MOVENET']} MoveNet cases, {n['STEM']} stem-kernel cases, seeds {args.seed0}..{seed - 1}", flush=True)
 
 
 if __name__ == "__main__":
