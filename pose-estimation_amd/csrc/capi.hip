@@ -32,6 +32,8 @@ int ph_launch_movenet_multipose(const float* center, const float* heat, const fl
                                 float* c_score, float* out, hipStream_t stream);
 int ph_conv_1x1_mw();
 bool ph_stem512_applies(const PhConvParams& p);
+bool ph_pair_enabled();                                           // conv_pair.hip: two 1x1 convs as one kernel
+int ph_launch_pair(const PhPairParams& q, hipStream_t stream);
 int ph_launch_lift3d(const float* kp, const int* n_people, int B, int maxp, int J, const uint16_t* depth, int Hd,
                      int Wd, double fx, double fy, double cx, double cy, double depth_scale, int po, double* out,
                      hipStream_t stream);
@@ -92,6 +94,10 @@ struct Op {
   double flops = 0.0;  // algorithmic, per frame
   bool skip = false;   // computed inside the next op's kernel (stem fusion)
   int* tile_ctr = nullptr;  // stem op: the persistent kernel's two tile counters
+  // 1x1 pair (conv_pair.hip): `pair_head` is computed inside the next op's kernel and `pair` runs that kernel
+  // whenever ph_pair_enabled(); both keep their own parameters for the separate launches
+  bool pair_head = false, pair = false;
+  PhPairParams pp;
 };
 
 struct ph_ctx {
@@ -544,6 +550,42 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       a.skip = true;
     }
   }
+  // 1x1 pair: a wide 1x1 conv (Mconv6: -> 256 / 512 channels) whose output is read only by the next, narrow 1x1
+  // conv (Mconv7: -> <= 64 channels) runs inside that conv's kernel, slab by slab through LDS; the wide map
+  // (123 MB at 32 x 46x82 x 512) is then neither written nor read
+  for (int i = 0; i + 1 < n_ops; i++) {
+    Op& a = c->ops[i];
+    Op& b = c->ops[i + 1];
+    if (a.d.type != PH_OP_CONV || b.d.type != PH_OP_CONV || a.skip || b.skip) continue;
+    if (a.d.kh != 1 || a.d.kw != 1 || b.d.kh != 1 || b.d.kw != 1 || a.variant != 6 || b.variant != 6) continue;
+    if (a.cp.debug || b.cp.debug || a.d.pool || b.d.pool) continue;
+    if (a.d.cout % 128 || a.d.cout > 512 || a.d.n_dst != 1 || a.d.f32_coff >= 0 || a.d.dst_coff[0] != 0) continue;
+    if (a.d.cin_read % 32 || a.d.cin_read < 96) continue;
+    const Buf& mid = c->bufs[a.d.dst_buf[0]];
+    if (b.d.in_buf != a.d.dst_buf[0] || b.d.in_coff != 0 || b.d.cin_read != a.d.cout || mid.d.channels != a.d.cout ||
+        b.d.cout > 64 || b.cp.Kpad != a.d.cout)
+      continue;
+    bool shared = false;
+    for (int j = 0; j < n_ops; j++)
+      if (j != i + 1 && c->ops[j].d.in_buf == a.d.dst_buf[0]) shared = true;
+    if (shared) continue;
+    PhPairParams& q = b.pp;
+    memset(&q, 0, sizeof(q));
+    q.a = a.cp;
+    q.wt2 = b.wt;
+    q.bias2 = b.bias;
+    q.slope2 = b.slope;
+    q.Kpad2 = b.cp.Kpad;
+    q.cout2 = b.d.cout;
+    q.act2 = b.d.act;
+    q.n_dst2 = b.cp.n_dst;
+    for (int k = 0; k < b.cp.n_dst; k++) q.dst2[k] = b.cp.dst[k];
+    q.f32_out2 = b.cp.f32_out;
+    q.f32_C2 = b.cp.f32_C;
+    q.f32_coff2 = b.cp.f32_coff;
+    a.pair_head = true;
+    b.pair = true;
+  }
   c->op_ev.resize(n_ops + 1);
   for (auto& e : c->op_ev) PH_CHECK(hipEventCreate(&e));
   c->cur_out = c->net_out;
@@ -585,11 +627,18 @@ static int run_ops(ph_ctx* c, int B, bool timed) {
     return -1;
   }
   PH_CHECK(hipSetDevice(c->device));
+  const bool pairs = ph_pair_enabled();
   for (size_t i = 0; i < c->ops.size(); i++) {
     Op& o = c->ops[i];
     if (timed) PH_CHECK(hipEventRecord(c->op_ev[i], c->stream));
     const Buf& in = c->bufs[o.d.in_buf];
-    if (o.skip) continue;
+    if (o.skip || (pairs && o.pair_head)) continue;
+    if (pairs && o.pair) {
+      o.pp.a.B = B;
+      o.pp.a.M = B * o.pp.a.H * o.pp.a.W;
+      if (ph_launch_pair(o.pp, c->stream)) return -1;
+      continue;
+    }
     if (o.d.type == PH_OP_POOL) {
       const Buf& ob = c->bufs[o.d.dst_buf[0]];
       if (ph_launch_maxpool(in.ptr, ob.ptr, B, in.d.height, in.d.width, in.d.channels, in.Hp(), in.Wp(),
@@ -643,7 +692,8 @@ int ph_op_kernel(ph_ctx* c, int op, char* name, int cap) {
     return -1;
   }
   const Op& o = c->ops[op];
-  if (o.skip) snprintf(name, cap, "(fused into the next op)");
+  if (o.skip || (o.pair_head && ph_pair_enabled())) snprintf(name, cap, "(fused into the next op)");
+  else if (o.pair && ph_pair_enabled()) snprintf(name, cap, "conv1x1_pair_kernel(PhPairParams)");
   else if (o.d.type == PH_OP_POOL) snprintf(name, cap, "maxpool2x2_kernel");
   else if (o.cp.stem && ph_stem512_applies(o.cp)) snprintf(name, cap, "conv_stem512_kernel(PhConvParams, int, int, int)");
   else if (o.cp.stem) snprintf(name, cap, "conv3x3_halo_kernel<2, 4, false, true, 9>");

@@ -58,6 +58,20 @@ struct PhConvParams {
   int debug;  // timing experiments only (POSEHIP_CONV_DEBUG): 1 skip A loads, 2 skip B loads, 4 skip MFMA
 };
 
+// Two consecutive 1x1 convs as one kernel (conv_pair.hip): `a` is the wide first layer (input, weights, bias,
+// activation; its destination is never written), the rest describes the narrow second layer (<= 64 channels).
+struct PhPairParams {
+  PhConvParams a;
+  const bf16* wt2;      // [cout_pad2][Kpad2], k = channel of the first layer's output
+  const float* bias2;
+  const float* slope2;
+  int Kpad2, cout2, act2;
+  int n_dst2;
+  PhDst dst2[PH_MAX_DST];
+  float* f32_out2;
+  int f32_C2, f32_coff2;
+};
+
 __host__ __device__ static inline unsigned ph_magic(unsigned d) {
   // ceil(2^32 / d): __umulhi(n, magic) == n / d whenever n * d < 2^32
   return (unsigned)((0x100000000ull + d - 1) / d);

@@ -243,6 +243,45 @@ def test_persistent_stem_kernel_equals_the_halo_stem(engine, H, W, B, monkeypatc
     assert np.abs(pooled[1]).max() > 0
 
 
+@pytest.mark.parametrize("model,H,W,B", [("body25", 64, 96, 3), ("body25", 368, 656, 2), ("coco", 80, 112, 2)])
+def test_pair_kernel_equals_the_separate_1x1_layers(engine, model, H, W, B, monkeypatch):
+    """conv1x1_pair_kernel (Mconv6 + Mconv7 of a stage as one launch, the wide map only ever in LDS) against the two
+    separate 1x1 launches (POSEHIP_PAIR_KERNEL=0, read at every forward): same operand roles, the intermediate rounded
+    to bf16 and the second layer's K walked in the same ascending 32-chunks, so every stage output -- the bf16 windows
+    the next stage reads and the fp32 network output -- is bit-equal.  Tiles ragged at the end and full size."""
+    from posehip import synth
+    proto = caffe_io.body25_prototxt(H, W) if model == "body25" else caffe_io.coco_prototxt(H, W)
+    net = caffe_io.parse_prototxt(proto)
+    weights = graph.random_weights(net, seed=17)
+    plan = graph.build_plan(net, weights)
+    engine.build(plan, B)
+    frames = synth.synth_frames(9, B, H, W)
+    outs, mids, n_pairs = [], [], 0
+    for flag in ("0", "1"):
+        monkeypatch.setenv("POSEHIP_PAIR_KERNEL", flag)
+        names = engine.op_kernels()
+        pair_ops = [i for i, k in enumerate(names) if k == "conv1x1_pair_kernel(PhPairParams)"]
+        if flag == "0":
+            assert not pair_ops
+        else:
+            n_pairs = len(pair_ops)
+            assert n_pairs >= 6 and all(names[i - 1] == "(fused into the next op)" for i in pair_ops)
+        for n in (B, 1, B):                     # a smaller batch in between: the tile count follows it
+            engine.preprocess(frames[:n], _ffi.PH_PRE_NATIVE)
+            engine.forward(n)
+        outs.append(engine.net_out(B))
+        if flag == "1":
+            dsts = {plan.ops[i]["dst"][0][0] for i in pair_ops if plan.ops[i]["dst"]}
+        else:
+            dsts = {op["dst"][0][0] for op in plan.ops if op.get("k", 0) == 1 and op["dst"] and op.get("cout", 999) <= 64}
+        mids.append({d: engine.get_buffer(d) for d in sorted(dsts)})
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert mids[1]
+    for d, got in mids[1].items():
+        np.testing.assert_array_equal(mids[0][d], got)
+
+
 def test_coco_full_size_forward_and_v1_decode(engine):
     """BASELINE configs[2] geometry: the COCO-18 graph (7x7 refinement stages on the im2col kernel) at 368x656,
     B = 2, against the torch fp32 oracle; then the V1 decode (postprocess_multi semantics, 1920x1080 target) of the
