@@ -586,6 +586,31 @@ __device__ __forceinline__ int v1_piece_at(const V1Grid& g, int x, int y) {
   return (lo > r0 && g.srun[lo - 1].y >= x) ? lo - 1 : -1;
 }
 
+// The same for a caller that probes neighbouring pixels one after the other (border following, outline chains): `rel`
+// = position inside its row of the first piece that starts right of the last probe.  Pieces of adjacent rows of a
+// blob line up, so the guess is almost always right, and checking it costs two dependent LDS reads (the row's offsets,
+// then the two pieces around the guess) instead of the binary search's five to seven.
+__device__ __forceinline__ int v1_piece_near(const V1Grid& g, int x, int y, int& rel) {
+  if (x < 0 || y < 0 || x >= g.W || y >= g.H) return -1;
+  const int r0 = g.rowoff[y], r1 = g.rowoff[y + 1];
+  int q = r0 + rel;
+  q = q < r0 ? r0 : (q > r1 ? r1 : q);
+  const short2 a = q > r0 ? g.srun[q - 1] : make_short2(-32768, -32768);
+  const short2 b = q < r1 ? g.srun[q] : make_short2(32767, 32767);
+  if (a.x <= x && x < b.x) {   // q is the first piece with xs > x
+    rel = q - r0;
+    return a.y >= x ? q - 1 : -1;
+  }
+  int lo = r0, hi = r1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (g.srun[mid].x <= x) lo = mid + 1;
+    else hi = mid;
+  }
+  rel = lo - r0;
+  return (lo > r0 && g.srun[lo - 1].y >= x) ? lo - 1 : -1;
+}
+
 // the smoothed map at one pixel, with the operations of v1_runs_kernel (resize, row pass, column pass)
 __device__ float v1_smooth_at(const float* src, int hs, int ws, int W, int H, int x, int y) {
   float t[3];
@@ -651,7 +676,8 @@ __device__ int v1_trace(const V1Grid& g, int x0, int y0, bool is_hole, unsigned 
   int s_end = is_hole ? 0 : 4;
   // the library looks clockwise from s_end - 1 for the first set neighbour; reaching s_end again = single pixel
   int s = (s_end - 1 - r) & 7;
-  unsigned hit = v1_gballot(r < 7 && v1_piece_at(g, x0 + v1_dx(s), y0 + v1_dy(s)) >= 0, lane);
+  int rel = 0;                       // this lane's guess for v1_piece_near
+  unsigned hit = v1_gballot(r < 7 && v1_piece_near(g, x0 + v1_dx(s), y0 + v1_dy(s), rel) >= 0, lane);
   int j3 = v1_piece_at(g, x0, y0);   // piece of the current border pixel
   if (!hit) {
     if (r == 0) {
@@ -669,13 +695,12 @@ __device__ int v1_trace(const V1Grid& g, int x0, int y0, bool is_hole, unsigned 
   for (; guard < V1_TRACE_CAP; guard++) {
     s_end = s;
     const int sk = (s_end + 1 + r) & 7;   // lane r: the (r+1)-th direction of the counter-clockwise search
-    const int px = i3x + v1_dx(sk), py = i3y + v1_dy(sk);
-    const int jk = v1_piece_at(g, px, py);
+    const int jk = v1_piece_near(g, i3x + v1_dx(sk), i3y + v1_dy(sk), rel);
     hit = v1_gballot(jk >= 0, lane);
     if (!hit) return -1;                  // (cannot happen: the pixel the walk came from is set)
     const int k0 = __ffs(hit) - 1;
     s = (s_end + 1 + k0) & 7;
-    const int i4x = __shfl(px, k0, 8), i4y = __shfl(py, k0, 8), j4 = __shfl(jk, k0, 8);
+    const int i4x = i3x + v1_dx(s), i4y = i3y + v1_dy(s), j4 = __shfl(jk, k0, 8);   // lane k0's probe
     if ((unsigned)(s - 1) < (unsigned)s_end && r == 0) mark[j3] = cid;
     if (s != prev_s) {
       if (r == 0 && ok) ok = verts.push(n, make_short2((short)i3x, (short)i3y));
@@ -771,25 +796,51 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
     int edges = n;
     int e_idx[2] = {imin, imin}, e_ye[2] = {ymin, ymin}, e_di[2] = {1, n - 1};
     long long e_x[2] = {-XY_ONE, -XY_ONE}, e_dx[2] = {0, 0};
+    // The walkers read the vertices in order, one forwards, one backwards, and the pool is in global memory: lane k
+    // of the group fetches the k-th vertex ahead, the others take it by shuffle -- one memory latency per eight
+    // vertices instead of one each.
+    const short2 vtop = v[imin];
+    short2 e_v[2] = {vtop, vtop};   // the vertex at e_idx
+    int wbase[2] = {-1, -1};
+    int wbuf[2] = {0, 0};
+    auto vert = [&](int i, int idx) -> short2 {
+      int off = i == 0 ? idx - wbase[0] : wbase[1] - idx;
+      off = off < 0 ? off + n : off;
+      if (wbase[i] < 0 || off >= 8) {   // (uniform within the group)
+        wbase[i] = idx;
+        int j = i == 0 ? idx + r : idx - r + 8 * n;
+        j %= n;
+        const short2 q = v[j];
+        wbuf[i] = ((int)(unsigned short)q.y << 16) | (int)(unsigned short)q.x;
+        off = 0;
+      }
+      const int raw = __shfl(wbuf[i], off, 8);
+      return make_short2((short)(raw & 0xffff), (short)(raw >> 16));
+    };
+    const bool narrow = W < 16000;      // (xe - xs) * 2 then fits 32 bits: same quotient from the cheaper division
     int y = ymin, cnt = 0, my_y = -1, my_x1 = 1, my_x2 = 0;
     do {
       for (int i = 0; i < 2; i++) {
         if (y >= e_ye[i]) {
-          int idx0 = e_idx[i];
+          short2 q0 = e_v[i];
           const int di = e_di[i];
-          int idx = idx0 + di;
+          int idx = e_idx[i] + di;
           if (idx >= n) idx -= n;
           for (; edges-- > 0;) {
-            const int ty = v[idx].y;
+            const short2 q = vert(i, idx);
+            const int ty = q.y;
             if (ty > y) {
-              const long long xs = (long long)v[idx0].x << 16, xe = (long long)v[idx].x << 16;
+              const long long xs = (long long)q0.x << 16, xe = (long long)q.x << 16;
               e_ye[i] = ty;
-              e_dx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));   // C division: towards zero, as the library's
+              // C division: towards zero, as the library's
+              if (narrow) e_dx[i] = (long long)(((int)(xe - xs) * 2 + (ty - y)) / (2 * (ty - y)));
+              else e_dx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
               e_x[i] = xs;
               e_idx[i] = idx;
+              e_v[i] = q;
               break;
             }
-            idx0 = idx;
+            q0 = q;
             idx += di;
             if (idx >= n) idx -= n;
           }
@@ -822,6 +873,7 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
     if (r == 0) v1_paint_span(p, v[0].y, v[0].x, v[0].x);
   } else {
     int cj = -1, cy = -1;  // piece of the previous outline pixel
+    int rel = 0;
     for (int e = r; e < n; e += 8) {
       const short2 a = v[e == 0 ? n - 1 : e - 1], c = v[e];
       const int dx = c.x - a.x, dy = c.y - a.y;
@@ -833,7 +885,7 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
         for (int t = 1; t <= steps; t++) {
           const int x = a.x + t * sx, y = a.y + t * sy;
           if (!(cj >= 0 && y == cy && p.g.srun[cj].x <= x && x <= p.g.srun[cj].y)) {
-            cj = v1_piece_at(p.g, x, y);
+            cj = v1_piece_near(p.g, x, y, rel);
             cy = y;
           }
           if (cj >= 0) v1_consider(p, cj, y, x, x);
@@ -846,8 +898,10 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
 }
 
 // ---------------------------------------------------------------------------
-// K-B: blobs from runs.  grid (n_parts, B), block 256
+// K-B: blobs from runs.  grid (n_parts, B), block V1B_THREADS (8 waves: a (frame, part) plane of a crowded 1080p
+// scene has 5-6 blobs that need the literal walk, and walks that share a wave run one after the other)
 // ---------------------------------------------------------------------------
+#define V1B_THREADS 512
 __device__ __forceinline__ int uf_find(volatile int* parent, int i) {
   int p = parent[i];
   while (p != i) {
@@ -871,7 +925,7 @@ __device__ void uf_union(int* parent, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__ net_out, int C, int hs, int ws, int W,
+__global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __restrict__ net_out, int C, int hs, int ws, int W,
                                                        int H, int n_parts, int run_cap, int kp_cap, int vert_cap,
                                                        const int* __restrict__ n_runs, const V1Run* __restrict__ runs,
                                                        unsigned long long* __restrict__ ws_best,
@@ -912,16 +966,16 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   unsigned short* irr = (unsigned short*)(c_depth + kp_cap);   // blobs that need the literal walk
   unsigned char* c_hole = (unsigned char*)(irr + kp_cap);
   __shared__ int s_nroot, s_nirr, s_ncont, s_vused;
-  __shared__ int s_scan[256];
+  __shared__ int s_scan[V1B_THREADS];
 
-  for (int i = tid; i < H + 2; i += 256) rowoff[i] = 0;
+  for (int i = tid; i < H + 2; i += V1B_THREADS) rowoff[i] = 0;
   if (tid == 0) {
     s_nroot = 0;
     s_nirr = 0;
     s_vused = 0;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += V1B_THREADS) {
     parent[i] = i;
     mark[i] = 0;
     atomicAdd(&rowoff[R[i].y + 1], 1);
@@ -934,7 +988,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   __syncthreads();
   // exclusive scan of the per-row counts (rowoff[y+1] = count of row y)
   {
-    const int per = (H + 1 + 255) / 256;
+    const int per = (H + 1 + V1B_THREADS - 1) / V1B_THREADS;
     const int lo = tid * per, hi = lo + per < H + 1 ? lo + per : H + 1;
     int s = 0;
     for (int i = lo; i < hi; i++) s += rowoff[i + 1];
@@ -942,7 +996,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
     __syncthreads();
     if (tid == 0) {
       int acc = 0;
-      for (int i = 0; i < 256; i++) {
+      for (int i = 0; i < V1B_THREADS; i++) {
         const int t = s_scan[i];
         s_scan[i] = acc;
         acc += t;
@@ -959,7 +1013,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   __syncthreads();
   // rowoff[y+1] now = start of row y; scatter with a moving cursor: afterwards rowoff[y+1] = end of row y = start
   // of row y+1, so row y spans [rowoff[y], rowoff[y+1]) with rowoff[0] = 0 (row -1 is empty)
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += V1B_THREADS) {
     const V1Run r = R[i];
     const int pos = atomicAdd(&rowoff[r.y + 1], 1);
     byrow[pos] = (unsigned short)i;
@@ -967,7 +1021,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
     bval[pos] = r.best;
   }
   __syncthreads();
-  for (int y = tid; y < H; y += 256) {   // order each row by xs (a handful of pieces: insertion sort)
+  for (int y = tid; y < H; y += V1B_THREADS) {   // order each row by xs (a handful of pieces: insertion sort)
     const int lo = rowoff[y], hi = rowoff[y + 1];
     for (int a = lo + 1; a < hi; a++) {
       const short2 sv = srun[a];
@@ -987,7 +1041,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   }
   __syncthreads();
   // union pieces that touch: same row across a tile seam (xs == left neighbour's xe + 1); previous row: 8-connectivity
-  for (int j = tid; j < n; j += 256) {
+  for (int j = tid; j < n; j += V1B_THREADS) {
     const int y = R[byrow[j]].y;
     const short2 r = srun[j];
     if (j > rowoff[y] && srun[j - 1].y + 1 == r.x) uf_union(parent, j, j - 1);
@@ -999,7 +1053,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
       }
   }
   __syncthreads();
-  for (int j = tid; j < n; j += 256) {   // full path compression: parent[j] = the blob's root from here on
+  for (int j = tid; j < n; j += V1B_THREADS) {   // full path compression: parent[j] = the blob's root from here on
     const int root = uf_find(parent, j);
     parent[j] = root;                    // (concurrent finds read either an ancestor or the root: both lead there)
   }
@@ -1007,7 +1061,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   // per-blob first-raster maximum, first pixel, last row and number of (seam-merged) runs
   int* ymaxv = first + run_cap;
   int* nrunv = first + 2 * run_cap;
-  for (int j = tid; j < n; j += 256) {
+  for (int j = tid; j < n; j += V1B_THREADS) {
     const int root = parent[j];
     const V1Run r = R[byrow[j]];
     const unsigned pos = (unsigned)(r.y * W + r.bx);
@@ -1028,7 +1082,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   // the contour table starts with the blobs' outer borders; blobs with more than one run in some row need the
   // literal contour + fill (see the helpers' header), every other blob's keypoint is its component's arg-max
   if (tid == 0) s_ncont = nr;
-  for (int i = tid; i < nr; i += 256) {
+  for (int i = tid; i < nr; i += V1B_THREADS) {
     const int me = roots[i];
     const int fp = ld(&first[me]);
     c_disc[i] = fp;
@@ -1050,12 +1104,12 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   if (nirr) {
     const V1Grid g = {srun, rowoff, W, H};
     V1Paint pt = {g, bval, byrow, R, plane, hs, ws, 0ull};
-    // blob k of the list -> thread (k % 4) * 64 + k / 4: spread over the four waves first
     V1Verts vv = {vpool, &s_vused, vert_cap, 0, 0};
     const int lane = tid & 63, r = tid & 7;
     // one group of 8 lanes per blob.  Groups of one wave that walk different blobs run one after the other (their
-    // control flow differs), so consecutive blobs go to different WAVES first: blob k -> wave k % 4, group k / 4 % 8
-    for (int k = ((tid >> 3) & 7) * 4 + (tid >> 6); k < nirr; k += 32) {
+    // control flow differs), so consecutive blobs go to different WAVES first: blob k -> wave k % NW, group k / NW % 8
+    constexpr int NW = V1B_THREADS / 64;
+    for (int k = ((tid >> 3) & 7) * NW + (tid >> 6); k < nirr; k += 8 * NW) {
       const int i = irr[k], me = roots[i];
       const int fp = c_disc[i], y_first = fp / W, y_last = ld(&ymaxv[me]);
       int c = i, sx = fp - y_first * W, sy = y_first;   // the outer border starts at the blob's first raster pixel
@@ -1126,7 +1180,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
     // parents of the outer borders (RETR_TREE): the border met last on the first pixel's row = the one that
     // right-marked the nearest run end to its left; a hole border is the parent itself, an outer border hands on
     // its own parent (its first pixel comes earlier in raster order, so the chain ends)
-    for (int X = tid; X < nr; X += 256) {
+    for (int X = tid; X < nr; X += V1B_THREADS) {
       const int fp = c_disc[X], y0 = fp / W, x0 = fp - y0 * W;
       const int j0 = v1_piece_at({srun, rowoff, W, H}, x0, y0);
       int link = -1;
@@ -1141,13 +1195,13 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
       c_link[X] = (short)link;
     }
     __syncthreads();
-    for (int X = tid; X < nr; X += 256) {
+    for (int X = tid; X < nr; X += V1B_THREADS) {
       int p = c_link[X];
       while (p >= 0 && !c_hole[p]) p = c_link[p];
       c_par[X] = (short)p;
     }
     __syncthreads();
-    for (int X = tid; X < nc; X += 256) {
+    for (int X = tid; X < nc; X += V1B_THREADS) {
       int d = 0;
       for (int p = c_par[X]; p >= 0; p = c_par[p]) d++;
       c_depth[X] = (short)d;
@@ -1156,7 +1210,7 @@ __global__ __launch_bounds__(256) void v1_blobs_kernel(const float* __restrict__
   }
   // list order of cvTreeToNodeSeq: a node, its children, its next sibling; siblings latest-discovered first.  A
   // contour's place = the number of contours that come before it.
-  for (int a = tid; a < nc; a += 256) {
+  for (int a = tid; a < nc; a += V1B_THREADS) {
     int rank = 0;
     if (nc == nr) {
       const int da = c_disc[a];
@@ -1438,7 +1492,7 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
                        net_out, C, hs, ws, W, H, thr, m.n_parts, c.run_cap, (int)(ldsA2 / 4), w.n_runs, w.runs, w.overflow);
   }
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
-  hipLaunchKernelGGL(v1_blobs_kernel, dim3(m.n_parts, B), dim3(256), ldsB, stream, net_out, C, hs, ws, W, H, m.n_parts,
+  hipLaunchKernelGGL(v1_blobs_kernel, dim3(m.n_parts, B), dim3(V1B_THREADS), ldsB, stream, net_out, C, hs, ws, W, H, m.n_parts,
                      c.run_cap, c.kp_cap, V1_VERT_POOL(c.run_cap), (const int*)w.n_runs, (const V1Run*)w.runs, w.ws_best,
                      w.ws_first, w.ws_verts, w.kps, w.n_kps, w.overflow);
   if (ev) PH_CHECK(hipEventRecord(ev[2], stream));

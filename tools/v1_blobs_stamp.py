@@ -18,6 +18,14 @@ eng.set_net_out(np.stack([synth.synth_net_output(2000 * P + i, P, COCO_18, 46, 8
 L = _ffi.lib(); cyc = (ctypes.c_ulonglong * 16)()
 for _ in range(3):
     eng.decode_v1(bp, pp, MAPIDX, B, 1920, 1080, 0.1, kp_cap=256, person_cap=1024)
+if not hasattr(L, "ph_debug_v1_blobs"):      # a build without the stamps: kernel times only (median of 9)
+    ts = []
+    for _ in range(9):
+        eng.decode_v1(bp, pp, MAPIDX, B, 1920, 1080, 0.1, kp_cap=256, person_cap=1024)
+        ts.append(eng.decode_v1_times())
+    med = [sorted(t[i] for t in ts)[4] for i in range(3)]
+    print("kernel ms (runs, blobs, pairs+assemble), median of 9:", [round(t, 3) for t in med], "sum", round(sum(med), 3))
+    sys.exit(0)
 L.ph_debug_v1_blobs(cyc, 1)
 eng.decode_v1(bp, pp, MAPIDX, B, 1920, 1080, 0.1, kp_cap=256, person_cap=1024)
 L.ph_debug_v1_blobs(cyc, 0)
