@@ -222,7 +222,7 @@ static void free_v2(ph_ctx* c) {
 }
 
 static void free_v1(ph_ctx* c) {
-  void* ptrs[] = {c->v1.n_runs, c->v1.runs,    c->v1.ws_best, c->v1.ws_first,  c->v1.kps,     c->v1.n_kps,
+  void* ptrs[] = {c->v1.n_runs, c->v1.runs,    c->v1.kps,     c->v1.n_kps,
                   c->v1.pairs,  c->v1.n_pairs, c->v1.persons, c->v1.n_persons, c->v1.overflow, c->v1.ws_verts};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1258,8 +1258,6 @@ int ph_decode_v1(ph_ctx* c, const ph_v1_model* m, int B, int W0, int H0, float c
     ph_v1_sizes(dev, B, W0, H0, caps, &c->v1sz);
     PH_CHECK(hipMalloc(&c->v1.n_runs, c->v1sz.n_runs));
     PH_CHECK(hipMalloc(&c->v1.runs, c->v1sz.runs));
-    PH_CHECK(hipMalloc(&c->v1.ws_best, c->v1sz.ws_best));
-    PH_CHECK(hipMalloc(&c->v1.ws_first, c->v1sz.ws_first));
     PH_CHECK(hipMalloc(&c->v1.ws_verts, c->v1sz.ws_verts));
     PH_CHECK(hipMalloc(&c->v1.kps, c->v1sz.kps));
     PH_CHECK(hipMalloc(&c->v1.n_kps, c->v1sz.n_kps));

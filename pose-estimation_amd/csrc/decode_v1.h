@@ -26,14 +26,12 @@ struct V1Caps {
 };
 
 struct V1Sizes {
-  size_t n_runs, runs, ws_best, ws_first, ws_verts, kps, n_kps, pairs, n_pairs, persons, n_persons;
+  size_t n_runs, runs, ws_verts, kps, n_kps, pairs, n_pairs, persons, n_persons;
 };
 
 struct V1Buffers {
   int* n_runs;
   V1Run* runs;
-  unsigned long long* ws_best;
-  int* ws_first;
   short2* ws_verts;
   float* kps;
   int* n_kps;

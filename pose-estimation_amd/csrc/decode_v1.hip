@@ -928,8 +928,7 @@ __device__ void uf_union(int* parent, int a, int b) {
 __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __restrict__ net_out, int C, int hs, int ws, int W,
                                                        int H, int n_parts, int run_cap, int kp_cap, int vert_cap,
                                                        const int* __restrict__ n_runs, const V1Run* __restrict__ runs,
-                                                       unsigned long long* __restrict__ ws_best,
-                                                       int* __restrict__ ws_first, short2* __restrict__ ws_verts,
+                                                       short2* __restrict__ ws_verts,
                                                        float* __restrict__ kps, int* __restrict__ n_kps,
                                                        int* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) int ismem[];
@@ -945,8 +944,6 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
     return;
   }
   const V1Run* R = runs + ((size_t)b * n_parts + part) * run_cap;
-  unsigned long long* best = ws_best + ((size_t)b * n_parts + part) * run_cap;
-  int* first = ws_first + ((size_t)b * n_parts + part) * run_cap * 3;
   short2* vpool = ws_verts + ((size_t)b * n_parts + part) * vert_cap;
   // LDS: the mask as pieces sorted by (row, xs); every table below is indexed by sorted position
   int* parent = ismem;                                          // run_cap: union-find, then each piece's blob root
@@ -965,8 +962,13 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
   short* c_depth = c_link + kp_cap;
   unsigned short* irr = (unsigned short*)(c_depth + kp_cap);   // blobs that need the literal walk
   unsigned char* c_hole = (unsigned char*)(irr + kp_cap);
+  // per blob (position in roots[]): first-raster maximum, first pixel, last row, number of (seam-merged) runs
+  unsigned long long* b_best = (unsigned long long*)up(c_hole + kp_cap, 8);
+  int* b_first = (int*)(b_best + kp_cap);
+  int* b_ymax = b_first + kp_cap;
+  int* b_nrun = b_ymax + kp_cap;
   __shared__ int s_nroot, s_nirr, s_ncont, s_vused;
-  __shared__ int s_scan[V1B_THREADS];
+  __shared__ int s_wsum[V1B_THREADS / 64];
 
   for (int i = tid; i < H + 2; i += V1B_THREADS) rowoff[i] = 0;
   if (tid == 0) {
@@ -979,31 +981,23 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
     parent[i] = i;
     mark[i] = 0;
     atomicAdd(&rowoff[R[i].y + 1], 1);
-    best[i] = 0ull;
-    first[i] = 0x7fffffff;
-    first[run_cap + i] = -1;      // last row of the blob rooted here
-    first[2 * run_cap + i] = 0;   // its number of runs
   }
-  __threadfence();  // the initial values must be in L2 before any atomic of the statistics step lands there
   __syncthreads();
   // exclusive scan of the per-row counts (rowoff[y+1] = count of row y)
   {
     const int per = (H + 1 + V1B_THREADS - 1) / V1B_THREADS;
     const int lo = tid * per, hi = lo + per < H + 1 ? lo + per : H + 1;
-    int s = 0;
-    for (int i = lo; i < hi; i++) s += rowoff[i + 1];
-    s_scan[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-      int acc = 0;
-      for (int i = 0; i < V1B_THREADS; i++) {
-        const int t = s_scan[i];
-        s_scan[i] = acc;
-        acc += t;
-      }
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += rowoff[i + 1];
+    int v = sum;   // inclusive scan over the block: inside the wave by shuffles, wave totals through LDS
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(v, o);
+      if ((tid & 63) >= o) v += t;
     }
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = v;
     __syncthreads();
-    int acc = s_scan[tid];
+    int acc = v - sum;
+    for (int w = 0; w < (tid >> 6); w++) acc += s_wsum[w];
     for (int i = lo; i < hi; i++) {
       const int t = rowoff[i + 1];
       rowoff[i + 1] = acc;   // start offset of row i
@@ -1058,39 +1052,52 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
     parent[j] = root;                    // (concurrent finds read either an ancestor or the root: both lead there)
   }
   __syncthreads();
-  // per-blob first-raster maximum, first pixel, last row and number of (seam-merged) runs
-  int* ymaxv = first + run_cap;
-  int* nrunv = first + 2 * run_cap;
-  for (int j = tid; j < n; j += V1B_THREADS) {
-    const int root = parent[j];
-    const V1Run r = R[byrow[j]];
-    const unsigned pos = (unsigned)(r.y * W + r.bx);
-    atomicMax(&best[root], ((unsigned long long)__float_as_uint(r.best) << 32) | (0xffffffffu - pos));
-    atomicMin(&first[root], r.y * W + r.xs);
-    atomicMax(&ymaxv[root], r.y);
-    if (!(j > rowoff[r.y] && srun[j - 1].y + 1 == r.xs)) atomicAdd(&nrunv[root], 1);
-    if (root == j) {
+  // the blobs = the roots, in any order; a root's piece carries its blob's number (complemented) for a moment so
+  // that every piece finds it in one step
+  for (int j = tid; j < n; j += V1B_THREADS)
+    if (parent[j] == j) {
       const int s = atomicAdd(&s_nroot, 1);
       if (s < kp_cap) roots[s] = j; else *overflow = 1;
     }
-  }
-  __threadfence_block();
   __syncthreads();
   const int nr = s_nroot < kp_cap ? s_nroot : kp_cap;
-  auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  for (int i = tid; i < nr; i += V1B_THREADS) {
+    b_best[i] = 0ull;
+    b_first[i] = 0x7fffffff;
+    b_ymax[i] = -1;
+    b_nrun[i] = 0;
+    parent[roots[i]] = ~i;
+  }
+  __syncthreads();
+  // per-blob first-raster maximum, first pixel, last row and number of (seam-merged) runs: LDS atomics
+  for (int j = tid; j < n; j += V1B_THREADS) {
+    int id = parent[j];
+    if (id >= 0) {
+      id = parent[id];
+      if (id >= 0) continue;   // a blob beyond kp_cap (overflow is set)
+    }
+    id = ~id;
+    const V1Run r = R[byrow[j]];
+    const unsigned pos = (unsigned)(r.y * W + r.bx);
+    atomicMax(&b_best[id], ((unsigned long long)__float_as_uint(r.best) << 32) | (0xffffffffu - pos));
+    atomicMin(&b_first[id], r.y * W + r.xs);
+    atomicMax(&b_ymax[id], r.y);
+    if (!(j > rowoff[r.y] && srun[j - 1].y + 1 == r.xs)) atomicAdd(&b_nrun[id], 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < nr; i += V1B_THREADS) parent[roots[i]] = roots[i];
   const float* plane = net_out + ((size_t)b * C + part) * hs * ws;
   // the contour table starts with the blobs' outer borders; blobs with more than one run in some row need the
   // literal contour + fill (see the helpers' header), every other blob's keypoint is its component's arg-max
   if (tid == 0) s_ncont = nr;
   for (int i = tid; i < nr; i += V1B_THREADS) {
-    const int me = roots[i];
-    const int fp = ld(&first[me]);
+    const int fp = b_first[i];
     c_disc[i] = fp;
     c_par[i] = -1;
     c_link[i] = -1;
     c_hole[i] = 0;
-    c_key[i] = __hip_atomic_load(&best[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ld(&nrunv[me]) != ld(&ymaxv[me]) - fp / W + 1) irr[atomicAdd(&s_nirr, 1)] = (unsigned short)i;
+    c_key[i] = b_best[i];
+    if (b_nrun[i] != b_ymax[i] - fp / W + 1) irr[atomicAdd(&s_nirr, 1)] = (unsigned short)i;
   }
   __syncthreads();
   const int nirr = s_nirr;
@@ -1111,7 +1118,7 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
     constexpr int NW = V1B_THREADS / 64;
     for (int k = ((tid >> 3) & 7) * NW + (tid >> 6); k < nirr; k += 8 * NW) {
       const int i = irr[k], me = roots[i];
-      const int fp = c_disc[i], y_first = fp / W, y_last = ld(&ymaxv[me]);
+      const int fp = c_disc[i], y_first = fp / W, y_last = b_ymax[i];
       int c = i, sx = fp - y_first * W, sy = y_first;   // the outer border starts at the blob's first raster pixel
       bool hole = false;
       for (;;) {
@@ -1414,8 +1421,6 @@ __global__ __launch_bounds__(64) void v1_assemble_kernel(V1Model mdl, int kp_cap
 int ph_v1_sizes(const V1Model& m, int B, int W, int H, const V1Caps& c, V1Sizes* s) {
   s->n_runs = (size_t)B * m.n_parts * sizeof(int);
   s->runs = (size_t)B * m.n_parts * c.run_cap * sizeof(V1Run);
-  s->ws_best = (size_t)B * m.n_parts * c.run_cap * sizeof(unsigned long long);
-  s->ws_first = (size_t)B * m.n_parts * c.run_cap * 3 * sizeof(int);   // first pixel, last row, run count
   s->ws_verts = (size_t)B * m.n_parts * V1_VERT_POOL(c.run_cap) * sizeof(short2);   // contour vertices
   s->kps = (size_t)B * m.n_parts * c.kp_cap * 3 * sizeof(float);
   s->n_kps = (size_t)B * m.n_parts * sizeof(int);
@@ -1453,7 +1458,7 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
                        (size_t)(V1_TILE_H + 2) * V1_TILE_W + (size_t)V1_TILE_H * V1_TILE_W) * 4;
   // K-B: the sorted pieces (root, maximum, extents, run index, mark), row offsets, blob and contour tables
   const size_t ldsB = (size_t)c.run_cap * (4 + 4 + 4 + 2 + 2) + ((size_t)H + 2 + c.kp_cap) * 4 + 8 +
-                      (size_t)c.kp_cap * (8 + 4 + 2 + 2 + 2 + 2 + 1) + 16;
+                      (size_t)c.kp_cap * (8 + 4 + 2 + 2 + 2 + 2 + 1) + 16 + (size_t)c.kp_cap * (8 + 4 + 4 + 4) + 8;
   const size_t ldsC = (size_t)2 * hs * ws * 4;
   const size_t ldsD = (size_t)c.person_cap * (m.n_parts + 1) * 8;
   const size_t lim = 160 * 1024 - 8192;  // static __shared__ tables sit beside the dynamic region
@@ -1493,8 +1498,8 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   }
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(v1_blobs_kernel, dim3(m.n_parts, B), dim3(V1B_THREADS), ldsB, stream, net_out, C, hs, ws, W, H, m.n_parts,
-                     c.run_cap, c.kp_cap, V1_VERT_POOL(c.run_cap), (const int*)w.n_runs, (const V1Run*)w.runs, w.ws_best,
-                     w.ws_first, w.ws_verts, w.kps, w.n_kps, w.overflow);
+                     c.run_cap, c.kp_cap, V1_VERT_POOL(c.run_cap), (const int*)w.n_runs, (const V1Run*)w.runs,
+                     w.ws_verts, w.kps, w.n_kps, w.overflow);
   if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
   hipLaunchKernelGGL(v1_pairs_kernel, dim3(m.n_limbs, B), dim3(256), ldsC, stream, net_out, C, hs, ws, W, H, m,
                      c.kp_cap, (const float*)w.kps, (const int*)w.n_kps, w.pairs, w.n_pairs);

@@ -29,6 +29,8 @@ SHAPES = {  # name: (H, W, Cin, Cout, k)
     "m384_128": (46, 82, 384, 128, 3),
     "m6_512": (46, 82, 384, 512, 1),
     "m7_52": (46, 82, 512, 52, 1),
+    "pair512": (46, 82, 384, 512, 1, 52),   # Mconv6 + Mconv7 of a stage as the network runs them (conv1x1_pair_kernel;
+    "pair256": (46, 82, 288, 256, 1, 52),   # POSEHIP_PAIR_KERNEL=0: the two launches)
 }
 
 
@@ -42,7 +44,12 @@ def main():
     eng = Engine(0)
     B = args.batch
     for name in args.shapes.split(","):
-        H, W, cin, cout, k = SHAPES[name]
+        H, W, cin, cout, k = SHAPES[name][:5]
+        narrow = SHAPES[name][5] if len(SHAPES[name]) > 5 else 0
+        if not narrow:   # a single layer is what is measured: its 8-channel consumer must not be fused into it
+            os.environ["POSEHIP_PAIR_KERNEL"] = "0"
+        else:
+            os.environ.pop("POSEHIP_PAIR_KERNEL", None)
         txt = f'input: "image"\ninput_dim: 1\ninput_dim: 3\ninput_dim: {H}\ninput_dim: {W}\n'
         if name == "stem":
             txt += caffe_io._conv("c0", "image", cin, 3) + caffe_io._act("ReLU", "r0", "c0")
@@ -50,6 +57,10 @@ def main():
             txt += ('layer { name: "p1" type: "Pooling" bottom: "c1" top: "p1" pooling_param { pool: MAX kernel_size: 2 '
                     'stride: 2 } }\n')
             txt += caffe_io._conv("out", "p1", 8, 1)
+        elif narrow:
+            txt += caffe_io._conv("c0", "image", cin, 1) + caffe_io._act("ReLU", "r0", "c0")
+            txt += caffe_io._conv("c1", "c0", cout, k) + caffe_io._act("PReLU", "r1", "c1")
+            txt += caffe_io._conv("out", "c1", narrow, 1)
         else:
             txt += caffe_io._conv("c0", "image", cin, 1) + caffe_io._act("ReLU", "r0", "c0")
             txt += caffe_io._conv("c1", "c0", cout, k) + caffe_io._act("ReLU", "r1", "c1")
@@ -70,15 +81,16 @@ def main():
                 L.ph_debug_conv_cycles(cyc, 1)
             ms = eng.forward_timed(B)
             if r >= 3:
-                ts.append(ms[1])
+                ts.append(ms[1] + ms[2] if narrow else ms[1])
         if dbg:
             eng.sync()
             L.ph_debug_conv_cycles(cyc, 0)
             nb = max(1, cyc[4])
             print(f"  blocks {nb // args.reps}: prologue {cyc[0] / nb:.0f}  kloop {cyc[1] / nb:.0f} (wait {cyc[3] / nb:.0f})  epilogue {cyc[2] / nb:.0f} cycles/block")
         t = float(np.median(ts))
-        fl = 2.0 * k * k * cin * cout * H * W * B
-        print(f"{name:10s} {H}x{W} {cin:4d}->{cout:4d} k{k}: {t:8.4f} ms  {fl / t / 1e9:8.1f} TFLOP/s", flush=True)
+        fl = 2.0 * (k * k * cin * cout + cout * narrow) * H * W * B
+        print(f"{name:10s} {H}x{W} {cin:4d}->{cout:4d}{f'->{narrow}' if narrow else ''} k{k}: {t:8.4f} ms  {fl / t / 1e9:8.1f} TFLOP/s",
+              flush=True)
 
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@ python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/stats $O/hbm_traffic.j
 C1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 C2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 cd /tmp
-for s in conv4_2 conv3_2 m384_128 m128 m288_96 m96 m6_512 m7_52 stem; do   # one shape per run: a launch on its own
+for s in conv4_2 conv3_2 m384_128 m128 m288_96 m96 m6_512 m7_52 pair512 stem; do   # one shape per run: a launch on its own
   timeout -s KILL 120 rocprofv3 --pmc $C1 --output-format csv -d $O/pmc_conv_$s -- python3 $R/tools/conv_bench.py --reps 2 --shapes $s > $O/pmc_conv_$s.log 2>&1
 done
 BENCH_NO_H2D_LEG=1 timeout -s KILL 300 rocprofv3 --pmc $C2 --output-format csv -d $O/pmc_v2 -- python3 $R/bench.py --streams 1 --steps 2 --warmup 1 --cpu-frames 0 --sustained-steps 0 > $O/pmc_v2.log 2>&1
@@ -28,9 +28,9 @@ timeout -s KILL 300 rocprofv3 --pmc $C2 --output-format csv -d $O/pmc_v1 -- pyth
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/v1stats -- python3 $R/tools/coco_mot17_bench.py --steps 3 --people 60 > $O/v1stats.log 2>&1
 cd $R
 : > $O/pmc_conv.md
-for s in conv4_2 conv3_2 m384_128 m128 m288_96 m96 m6_512 m7_52 stem; do
+for s in conv4_2 conv3_2 m384_128 m128 m288_96 m96 m6_512 m7_52 pair512 stem; do
   echo "shape $s" >> $O/pmc_conv.md
-  python3 tools/pmc_table.py $O/pmc_conv_$s 'conv3x3|conv_stem' >> $O/pmc_conv.md
+  python3 tools/pmc_table.py $O/pmc_conv_$s 'conv3x3|conv_stem|conv1x1_pair' >> $O/pmc_conv.md
 done
 python3 tools/pmc_table.py $O/pmc_v2 'nms_|paf_|assemble|preprocess' > $O/pmc_v2.md
 python3 tools/pmc_table.py $O/pmc_v1 'v1_|preprocess' > $O/pmc_v1.md
