@@ -902,15 +902,17 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
 // scene has 5-6 blobs that need the literal walk, and walks that share a wave run one after the other)
 // ---------------------------------------------------------------------------
 #define V1B_THREADS 512
-__device__ __forceinline__ int uf_find(volatile int* parent, int i) {
-  int p = parent[i];
+__device__ __forceinline__ int uf_find(const int* parent, int i) {
+  // (relaxed atomic loads, not volatile ones: other threads hook roots meanwhile, and a volatile access keeps the
+  // pointer generic -- flat loads -- where the table is known to be in LDS)
+  int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   while (p != i) {
     i = p;
-    p = parent[i];
+    p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   return i;
 }
-__device__ void uf_union(int* parent, int a, int b) {
+__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   while (true) {
     a = uf_find(parent, a);
     b = uf_find(parent, b);
@@ -954,7 +956,12 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
   unsigned short* byrow = (unsigned short*)(srun + run_cap);    // run_cap: index in R
   unsigned short* mark = byrow + run_cap;                       // run_cap: contour id + 1 of the trace that last
                                                                 //          right-marked the piece's last pixel
-  auto up = [](void* p_, size_t a) { return (char*)(((size_t)p_ + a - 1) & ~(a - 1)); };
+  // (offsets from the LDS base, not integer casts of pointers: the tables then stay LDS pointers for the compiler --
+  // through a cast they became generic ones, read with flat loads at about twice the latency)
+  auto up = [&](const void* p_, size_t a) {
+    const size_t off = (size_t)((const char*)p_ - (const char*)ismem);
+    return (char*)ismem + ((off + a - 1) & ~(a - 1));
+  };
   unsigned long long* c_key = (unsigned long long*)up(mark + run_cap, 8);  // per contour: arg-max key
   int* c_disc = (int*)(c_key + kp_cap);          // discovery position (raster index of the border's start)
   short* c_par = (short*)(c_disc + kp_cap);      // parent contour, -1 = the frame
