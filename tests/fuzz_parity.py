@@ -328,18 +328,55 @@ def stem_case(eng, seed):
     return recipe + " ok"
 
 
+def pair_case(eng, seed):
+    """Round 3: conv1x1_pair_kernel (a wide 1x1 conv + the narrow 1x1 conv that alone reads it, one launch) against the
+    two separate launches, bit for bit: random input widths (incl. odd chunk counts), 1-4 slabs, any narrow width up to
+    64, every activation pair, ragged and sub-tile pixel counts; the narrow output both as fp32 network output and as
+    the bf16 window a further 3x3 conv reads."""
+    from posehip import caffe_io, graph, _ffi
+    rng = np.random.default_rng(seed)
+    H, W, B = int(rng.integers(3, 60)), int(rng.integers(3, 90)), int(rng.integers(1, 4))
+    cin = 32 * int(rng.integers(3, 13))
+    wide = 128 * int(rng.integers(1, 5))
+    narrow = int(rng.integers(1, 65))
+    acts = [None, "ReLU", "PReLU"]
+    a1, a2 = acts[int(rng.integers(0, 3))], acts[int(rng.integers(0, 3))]
+    txt = f'input: "image"\ninput_dim: 1\ninput_dim: 3\ninput_dim: {H}\ninput_dim: {W}\n'
+    txt += caffe_io._conv("f", "image", cin, 3) + caffe_io._act("ReLU", "rf", "f")
+    txt += caffe_io._conv("m6", "f", wide, 1) + (caffe_io._act(a1, "r6", "m6") if a1 else "")
+    txt += caffe_io._conv("m7", "m6", narrow, 1) + (caffe_io._act(a2, "r7", "m7") if a2 else "")
+    txt += caffe_io._concat("cat", ["f", "m7"])
+    txt += caffe_io._conv("tail", "cat", 16, 3)
+    txt += caffe_io._concat("net_output", ["m7", "tail"])
+    net = caffe_io.parse_prototxt(txt)
+    plan = graph.build_plan(net, graph.random_weights(net, seed, out_gain=1.0))
+    eng.build(plan, B)
+    frames = synth.synth_frames(seed, B, H, W)
+    got = []
+    for flag in ("0", "1"):
+        os.environ["POSEHIP_PAIR_KERNEL"] = flag
+        assert ("conv1x1_pair_kernel(PhPairParams)" in eng.op_kernels()) == (flag == "1"), eng.op_kernels()
+        eng.preprocess(frames, _ffi.PH_PRE_NATIVE)
+        eng.forward(B)
+        got.append(eng.net_out(B))
+    os.environ.pop("POSEHIP_PAIR_KERNEL", None)
+    recipe = f"PAIR seed={seed} {H}x{W} B={B} {cin}->{wide}({a1})->{narrow}({a2})"
+    assert np.array_equal(got[0], got[1]) and np.isfinite(got[1]).all() and np.abs(got[1]).max() > 0, recipe
+    return recipe + " ok"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=8.0)
     ap.add_argument("--seed0", type=int, default=0)
-    ap.add_argument("--only", type=str, default="", help="comma list of V2,V1,PRE,NET,POST,MOVENET,STEM")
+    ap.add_argument("--only", type=str, default="", help="comma list of V2,V1,PRE,NET,POST,MOVENET,STEM,PAIR")
     args = ap.parse_args()
     eng = Engine(0)
     t_end = time.time() + args.minutes * 60
-    n = {"V1": 0, "V2": 0, "PRE": 0, "NET": 0, "POST": 0, "MOVENET": 0, "STEM": 0}
+    n = {"V1": 0, "V2": 0, "PRE": 0, "NET": 0, "POST": 0, "MOVENET": 0, "STEM": 0, "PAIR": 0}
     seed = args.seed0
     while time.time() < t_end:
-        cases = ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE"), (net_case, "NET"), (post_case, "POST"), (movenet_case, "MOVENET"), (stem_case, "STEM"))
+        cases = ((v2_case, "V2"), (v1_case, "V1"), (pre_case, "PRE"), (net_case, "NET"), (post_case, "POST"), (movenet_case, "MOVENET"), (stem_case, "STEM"), (pair_case, "PAIR"))
         if args.only:
             cases = tuple(c for c in cases if c[1] in args.only.split(","))
         for fn, key in cases:
@@ -351,7 +388,7 @@ def main():
             n[key] += 1
             print(msg, flush=True)
         seed += 1
-    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, {n['NET']} network cases, {n['POST']} post-processing cases, {n['MOVENET']} MoveNet cases, {n['STEM']} stem-kernel cases, seeds {args.seed0}..{seed - 1}", flush=True)
+    print(f"fuzz ok: {n['V2']} V2 cases, {n['V1']} V1 cases, {n['PRE']} preprocess cases, {n['NET']} network cases, {n['POST']} post-processing cases, {n['MOVENET']} MoveNet cases, {n['STEM']} stem-kernel cases, {n['PAIR']} pair-kernel cases, seeds {args.seed0}..{seed - 1}", flush=True)
 
 
 if __name__ == "__main__":
