@@ -3,10 +3,12 @@
 // Caffe, openpose/opencv/skeleton.py:74-75, openpose/native/python/skeleton.py:447) as ONE kernel for gfx950.
 //
 // Why.  As two launches the wide intermediate map (512 channels x 120 704 pixels at batch 32 = 123 MB in bf16) is
-// written by the first and read back by the second, and the first is bound by exactly that: its blocks store 64 KB
-// each at the ~8 B/clk a CU sustains for stores while their 12-step K loops take a quarter of the time (30 % MFMA
-// busy); the second is 28 us of fixed cost around four K steps.  Here a block owns 256 pixels and walks the wide
-// layer's output in SLABS of 128 channels:
+// written by the first and read back by the second; both are far from the MFMA roof (30 % / 16 % busy): a 1x1 step
+// moves a whole pixel chunk + weight slice through the CU's load path per 16 MFMAs of a wave, and the second layer is
+// 25 us of fixed cost around four K steps.  Fusing them removes the 123 MB round trip and one launch, not that
+// bound: measured 89 us against 76 + 25 us, each alone on the chip (profiles/r03_pmc_conv_counters.md; DESIGN.md
+// section 9 has three further forms of this kernel that were built and did not beat it).  A block owns 256 pixels
+// and walks the wide layer's output in SLABS of 128 channels:
 //   for every slab:  K loop over the input chunks (pixel chunk + weight slice per step through 3-deep LDS rings, the
 //                    1x1 form of the halo kernel's pipeline) -> bias + activation -> the slab as bf16 in an LDS tile
 //                    -> the narrow layer's partial product with its 128 x 64 weight slab (4 K steps, 8 MFMAs each)
