@@ -7,7 +7,7 @@
 // moves a whole pixel chunk + weight slice through the CU's load path per 16 MFMAs of a wave, and the second layer is
 // 25 us of fixed cost around four K steps.  Fusing them removes the 123 MB round trip and one launch, not that
 // bound: measured 89 us against 76 + 25 us, each alone on the chip (profiles/r03_pmc_conv_counters.md; DESIGN.md
-// section 9 has three further forms of this kernel that were built and did not beat it).  A block owns 256 pixels
+// section 9 has four further forms of this kernel that were built and did not beat it).  A block owns 256 pixels
 // and walks the wide layer's output in SLABS of 128 channels:
 //   for every slab:  K loop over the input chunks (pixel chunk + weight slice per step through 3-deep LDS rings, the
 //                    1x1 form of the halo kernel's pipeline) -> bias + activation -> the slab as bf16 in an LDS tile
