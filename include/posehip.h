@@ -108,6 +108,11 @@ int ph_sync(ph_ctx* ctx);
 const char* ph_last_error(void);
 /* 1 when the library was built for the device it runs on (gfx950). */
 int ph_device_ok(int device);
+/* Page-locked host memory for result buffers that are filled again and again (hipHostMalloc / hipHostFree): device to
+ * host copies go straight to it instead of through the runtime's staging buffer.  No counterpart in the reference
+ * (cv2 / pyopenpose hand back fresh NumPy arrays, opencv/skeleton.py:154); used by Engine.decode_v1.  NULL on failure. */
+void* ph_host_alloc(int64_t bytes);
+int ph_host_free(void* ptr);
 
 /* ---- network (replaces net.setInput/net.forward, opencv/skeleton.py:74-75;
  *      the Caffe forward inside emplaceAndPop, native/python/skeleton.py:447) */

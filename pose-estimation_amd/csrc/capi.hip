@@ -255,6 +255,20 @@ int ph_sync(ph_ctx* c) {
   return 0;
 }
 
+void* ph_host_alloc(int64_t bytes) {
+  void* p = nullptr;
+  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+    ph_set_error("ph_host_alloc: %lld bytes of page-locked memory not available", (long long)bytes);
+    return nullptr;
+  }
+  return p;
+}
+
+int ph_host_free(void* ptr) {
+  if (ptr) PH_CHECK(hipHostFree(ptr));
+  return 0;
+}
+
 static int ensure_net_out(ph_ctx* c, size_t elems) {
   if (elems > c->net_out_elems) {
     if (c->net_out) PH_CHECK(hipFree(c->net_out));

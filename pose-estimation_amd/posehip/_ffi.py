@@ -61,6 +61,8 @@ SYMBOLS = {
     "ph_sync": (C.c_int, [_vp]),
     "ph_last_error": (C.c_char_p, []),
     "ph_device_ok": (C.c_int, [C.c_int]),
+    "ph_host_alloc": (_vp, [C.c_int64]),
+    "ph_host_free": (C.c_int, [_vp]),
     "ph_net_build": (C.c_int, [_vp, C.c_int, C.POINTER(PhBufDesc), C.c_int,
                                C.POINTER(PhOpDesc), C.c_int, C.c_int, C.c_int,
                                C.c_int]),

@@ -28,6 +28,7 @@ class Engine:
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
+            self._v1_release()
             self._lib.ph_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -274,24 +275,49 @@ class Engine:
         returns them (openpose/opencv/skeleton.py:154)."""
         m = _ffi.v1_model_struct(body_parts, pose_pairs, mapidx)
         P, L = m.n_parts, m.n_limbs
-        n_kps = np.zeros((B, P), np.int32)
-        kps = np.zeros((B, P, kp_cap, 3), np.float32)
-        n_pairs = np.zeros((B, L), np.int32)
-        pairs = np.zeros((B, L, kp_cap, 3), np.float64)
-        n_persons = np.zeros((B,), np.int32)
-        persons = np.zeros((B, person_cap, P + 1), np.float64)
+        n_kps, kps, n_pairs, pairs, n_persons, persons = self._v1_host(B, P, L, kp_cap, person_cap)
         _ffi.check(self._lib.ph_decode_v1(self._ctx, C.byref(m), int(B), int(W0), int(H0), float(conf_thres),
                                           int(kp_cap), int(person_cap), _ptr(n_kps), _ptr(kps), _ptr(n_pairs),
                                           _ptr(pairs), _ptr(n_persons), _ptr(persons)), "ph_decode_v1")
+        # everything handed back is a copy: the staging arrays are written again by the next call
+        live = np.arange(kp_cap)[None, None, :] < n_kps[:, :, None]
         out = []
         for b in range(B):
-            klist = np.concatenate([kps[b, p, :n_kps[b, p]] for p in range(P)], axis=0).astype(np.float64) \
-                if n_kps[b].sum() else np.zeros((0, 3))
-            people = [persons[b, i].copy() for i in range(n_persons[b])]
+            klist = kps[b][live[b]].astype(np.float64)          # parts in order, each part's keypoints in order
+            people = list(persons[b, :n_persons[b]].copy())
             valid = [pairs[b, k, :n_pairs[b, k]].copy() if n_pairs[b, k] >= 0 else [] for k in range(L)]
             invalid = [k for k in range(L) if n_pairs[b, k] < 0]
             out.append((klist, people, dict(n_kps=n_kps[b].copy(), valid_pairs=valid, invalid_pairs=invalid)))
         return out
+
+    def _v1_host(self, B, P, L, kp_cap, person_cap):
+        """Page-locked staging arrays (one ph_host_alloc region) for ph_decode_v1's results, kept per shape: the call copies ~10 MB of
+        capacity-sized tables, which through fresh pageable NumPy arrays (allocation, zero fill, the runtime's own
+        staging) cost more than the decode kernels at 20 people."""
+        key = (B, P, L, kp_cap, person_cap)
+        if getattr(self, "_v1_key", None) != key:
+            self._v1_release()
+            shapes = (((B, P), np.int32), ((B, P, kp_cap, 3), np.float32), ((B, L), np.int32),
+                      ((B, L, kp_cap, 3), np.float64), ((B,), np.int32), ((B, person_cap, P + 1), np.float64))
+            sizes = [(int(np.prod(sh)) * np.dtype(dt).itemsize + 255) // 256 * 256 for sh, dt in shapes]
+            total = sum(sizes)
+            ptr = self._lib.ph_host_alloc(total)
+            if not ptr:
+                _ffi.check(-1, "ph_host_alloc")
+            region = np.frombuffer((C.c_uint8 * total).from_address(ptr), np.uint8)
+            arrs, off = [], 0
+            for (sh, dt), sz in zip(shapes, sizes):
+                n = int(np.prod(sh)) * np.dtype(dt).itemsize
+                arrs.append(region[off:off + n].view(dt).reshape(sh))
+                off += sz
+            self._v1_arrs, self._v1_key, self._v1_ptr = tuple(arrs), key, ptr
+        return self._v1_arrs
+
+    def _v1_release(self):
+        if getattr(self, "_v1_ptr", None):
+            self._v1_arrs = ()                     # (no view may outlive the memory)
+            self._lib.ph_host_free(C.c_void_p(self._v1_ptr))
+        self._v1_arrs, self._v1_key, self._v1_ptr = (), None, None
 
     def decode_v1_times(self):
         ms = (C.c_float * 3)()
