@@ -5,8 +5,9 @@
 
 #define V1_MAX_PARTS 32
 #define V1_MAX_LIMBS 32
-// contour vertices one (frame, part) may hold at a time in the literal blob walk
-#define V1_VERT_POOL(run_cap) (8 * (run_cap))
+// 4-byte entries of a (frame, part)'s pool: the contour vertices of the literal blob walk (8 per run, as before the
+// fast walk existed: the one-group walk's share) + the tables, scratch vertices and fill tables of the fast walk
+#define V1_VERT_POOL(run_cap) (32 * (run_cap))
 
 struct V1Run {
   int y, xs, xe;  // row, first and last column of a run of mask pixels

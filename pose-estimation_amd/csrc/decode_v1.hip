@@ -558,13 +558,13 @@ struct V1Grid {
 
 #ifdef V1B_STAMP
 // Diagnostic build only (tools/v1_blobs_stamp.py): where v1_blobs_kernel spends its time.
-__device__ unsigned long long v1b_dbg[16];
+__device__ unsigned long long v1b_dbg[32];
 extern "C" int ph_debug_v1_blobs(unsigned long long* out, int reset) {
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[32] = {0};
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(v1b_dbg), z, sizeof(z));
   }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(v1b_dbg), 16 * sizeof(unsigned long long));
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(v1b_dbg), 32 * sizeof(unsigned long long));
 }
 #define V1B_ADD(i, v) atomicAdd(&v1b_dbg[i], (unsigned long long)(v))
 #define V1B_NOW() __builtin_readcyclecounter()
@@ -758,23 +758,26 @@ __device__ void v1_paint_span(V1Paint& p, int y, int x1, int x2) {
   }
 }
 
+template <int GW>
 __device__ __forceinline__ unsigned long long v1_gmax(unsigned long long k) {
-  for (int o = 1; o < 8; o <<= 1) {
-    const unsigned long long t = __shfl_xor(k, o, 8);
+  for (int o = 1; o < GW; o <<= 1) {
+    const unsigned long long t = __shfl_xor(k, o, GW);
     k = t > k ? t : k;
   }
   return k;
 }
 
 // FillConvexPoly (lineType 8, shift 0) of the contour v[0 .. n): the two edge walkers' span in every row from the
-// polygon's top row on, then the outline (the polygon's edges are straight 8-connected pixel chains).  One group:
-// every lane runs the walkers (a few additions per row), lane k paints the k-th row of each 8; outline edges are
-// dealt round-robin.  On return p.cur is the group's maximum in every lane.
+// polygon's top row on, then the outline (the polygon's edges are straight 8-connected pixel chains).  One group of
+// GW lanes (8: the one-group walk; 64: the wave of v1_fast_blob): every lane runs the walkers (a few additions per
+// row), lane k paints the k-th row of each GW; outline edges are dealt round-robin.  On return p.cur is the group's
+// maximum in every lane.
+template <int GW, bool FILL = true>
 __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
-  const int W = p.g.W, H = p.g.H, r = lane & 7;
+  const int W = p.g.W, H = p.g.H, r = lane & (GW - 1), r8 = lane & 7;
   const long long XY_ONE = 1 << 16;
   int xmin = 0x7fffffff, xmax = -0x7fffffff, ymax = -0x7fffffff, ykey = 0x7fffffff;   // ykey = (y << 16) | index
-  for (int i = r; i < n; i += 8) {
+  for (int i = r; i < n; i += GW) {
     const short2 q = v[i];
     const int k = ((int)q.y << 16) | i;
     ykey = k < ykey ? k : ykey;
@@ -782,22 +785,22 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
     xmax = xmax > q.x ? xmax : q.x;
     xmin = xmin < q.x ? xmin : q.x;
   }
-  for (int o = 1; o < 8; o <<= 1) {
-    const int a = __shfl_xor(ykey, o, 8), b = __shfl_xor(ymax, o, 8), c = __shfl_xor(xmax, o, 8),
-              d = __shfl_xor(xmin, o, 8);
+  for (int o = 1; o < GW; o <<= 1) {
+    const int a = __shfl_xor(ykey, o, GW), b = __shfl_xor(ymax, o, GW), c = __shfl_xor(xmax, o, GW),
+              d = __shfl_xor(xmin, o, GW);
     ykey = a < ykey ? a : ykey;
     ymax = b > ymax ? b : ymax;
     xmax = c > xmax ? c : xmax;
     xmin = d < xmin ? d : xmin;
   }
   const int ymin = ykey >> 16, imin = ykey & 0xffff;   // the first vertex of the top row
-  if (!(n < 3 || xmax < 0 || ymax < 0 || xmin >= W || ymin >= H)) {
+  if (FILL && !(n < 3 || xmax < 0 || ymax < 0 || xmin >= W || ymin >= H)) {
     ymax = ymax < H - 1 ? ymax : H - 1;
     int edges = n;
     int e_idx[2] = {imin, imin}, e_ye[2] = {ymin, ymin}, e_di[2] = {1, n - 1};
     long long e_x[2] = {-XY_ONE, -XY_ONE}, e_dx[2] = {0, 0};
     // The walkers read the vertices in order, one forwards, one backwards, and the pool is in global memory: lane k
-    // of the group fetches the k-th vertex ahead, the others take it by shuffle -- one memory latency per eight
+    // of every 8 fetches the k-th vertex ahead, the others take it by shuffle -- one memory latency per eight
     // vertices instead of one each.
     const short2 vtop = v[imin];
     short2 e_v[2] = {vtop, vtop};   // the vertex at e_idx
@@ -808,7 +811,7 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
       off = off < 0 ? off + n : off;
       if (wbase[i] < 0 || off >= 8) {   // (uniform within the group)
         wbase[i] = idx;
-        int j = i == 0 ? idx + r : idx - r + 8 * n;
+        int j = i == 0 ? idx + r8 : idx - r8 + 8 * n;
         j %= n;
         const short2 q = v[j];
         wbuf[i] = ((int)(unsigned short)q.y << 16) | (int)(unsigned short)q.x;
@@ -850,12 +853,12 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
       if (y >= 0) {
         const int left = e_x[0] > e_x[1] ? 1 : 0, right = 1 - left;
         int xx1 = (int)((e_x[left] + (XY_ONE >> 1)) >> 16), xx2 = (int)((e_x[right] + (XY_ONE >> 1)) >> 16);
-        if (xx2 >= 0 && xx1 < W && (cnt & 7) == r) {
+        if (xx2 >= 0 && xx1 < W && (cnt & (GW - 1)) == r) {
           my_y = y;
           my_x1 = xx1 < 0 ? 0 : xx1;
           my_x2 = xx2 >= W ? W - 1 : xx2;
         }
-        if ((++cnt & 7) == 0) {
+        if ((++cnt & (GW - 1)) == 0) {
           if (my_y >= 0) v1_paint_span(p, my_y, my_x1, my_x2);
           my_y = -1;
         }
@@ -864,7 +867,7 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
       e_x[1] += e_dx[1];
     } while (++y <= ymax);
     if (my_y >= 0) v1_paint_span(p, my_y, my_x1, my_x2);
-    p.cur = v1_gmax(p.cur);   // the outline's skip test starts from the whole fill's maximum
+    p.cur = v1_gmax<GW>(p.cur);   // the outline's skip test starts from the whole fill's maximum
     if (r == 0) V1B_ADD(14, ymax - ymin + 1);
   }
   [[maybe_unused]] const long long to_ = V1B_NOW();
@@ -874,7 +877,7 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
   } else {
     int cj = -1, cy = -1;  // piece of the previous outline pixel
     int rel = 0;
-    for (int e = r; e < n; e += 8) {
+    for (int e = r; e < n; e += GW) {
       const short2 a = v[e == 0 ? n - 1 : e - 1], c = v[e];
       const int dx = c.x - a.x, dy = c.y - a.y;
       if (dy == 0) {
@@ -893,8 +896,569 @@ __device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
       }
     }
   }
-  p.cur = v1_gmax(p.cur);
+  p.cur = v1_gmax<GW>(p.cur);
   if (r == 0) V1B_ADD(15, V1B_NOW() - to_);
+}
+
+// ---------------------------------------------------------------------------
+// All border loops of one blob at once, by one WAVE (the walk above follows one border pixel after the other with one
+// group of 8 lanes: ~2 000 cycles per pixel, and the largest blob of a plane was the kernel's critical path).
+//
+// A step of the library's border following is a function of its state alone -- the border pixel and the direction
+// `back` of the pixel the walk came from: it sweeps the neighbours counter-clockwise from back + 1 to the first set
+// one, emits the pixel if the move's direction differs from the last move's (= back ^ 4), right-marks the pixel if
+// the sweep passed an empty east neighbour, and moves.  Every border loop of the blob (outer and holes) is a cycle
+// of such states.  The states whose sweep passes an empty WEST or EAST neighbour are known without walking: the pixel
+// is a run's first / last pixel and `back` is the first set neighbour clockwise from that side (exactly the
+// library's search for a border's second pixel).  Between two of them the walk runs along the top or bottom of a
+// run: one or two steps on the staircases that blob borders are.  So:
+//   - every run end (a "crack": piece, side) is a node; one LANE per node walks its segment to the next node and
+//     records that node, the vertices the segment emits (into a scratch part of the vertex pool) and whether the
+//     node's own sweep passes the east side (a crack whose sweep starts at the other side of the same pixel is part
+//     of that node's step);
+//   - the cycles of the node graph are the border loops: the one through the blob's first pixel is the outer border,
+//     every other one a hole border, which the library starts at its first east crack in raster order (the first
+//     run end no earlier border has right-marked) -- a rotation of the cycle;
+//   - vertices are copied to their places in loop order, every piece gets the contour that swept its east crack as
+//     its mark, and the loops are filled by the wave's groups side by side.
+// The tables live in what the block's LDS has left over; a blob that does not fit (or trips one of the guards
+// below) is left untouched and goes through the one-group walk.
+// ---------------------------------------------------------------------------
+#define V1F_K 6          // vertices one segment may emit
+#define V1F_STEPS 16384  // steps of one segment (runaway guard)
+#define V1F_LOOPS 32     // border loops of one blob
+#define V1F_UNITS (10 + 2 * V1F_K)   // pool entries (4 B) the tables of one piece take at most
+
+struct V1FastCtx {
+  const int* parent;
+  unsigned short* mark;
+  char* lds;            // the block's dynamic LDS
+  int* s_free;          // first free byte of it
+  int lds_limit;
+  short2* vpool;
+  int* s_vused;
+  int vert_cap;         // entries of the pool
+  int fast_cap;         // ... the fast walk may fill it up to (the rest is the one-group walk's, as before)
+  int* ltab;            // LDS, this wave's: V1F_LOOPS x {vertices, first east piece, base, -}
+  int W, kp_cap;
+  int* s_ncont;
+  int* c_disc;
+  short* c_par;
+  short* c_link;
+  unsigned char* c_hole;
+  unsigned long long* c_key;
+  int* overflow;
+};
+
+__device__ __forceinline__ void v1_wave_sync() {
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int v1_wave_incl_scan(int v, int lane) {
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// compare-and-swap bump allocation (nothing is taken when it does not fit)
+__device__ __forceinline__ int v1_bump(int* ctr, int need, int limit) {
+  int old = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (true) {
+    if (old + need > limit) return -1;
+    const int prev = atomicCAS(ctr, old, old + need);
+    if (prev == old) return old;
+    old = prev;
+  }
+}
+
+// tables in global memory that one lane writes and another reads: loads that do not stop at the CU's cache
+template <typename T>
+__device__ __forceinline__ T v1_gl(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// columns x-1, x, x+1 of row y: which are mask pixels (bits 0..2) and in which pieces.  `rel` = the caller's guess:
+// position inside the row of the first piece that starts right of x + 1 (checked with the three reads it costs)
+__device__ __forceinline__ int v1_row3(const V1Grid& g, int x, int y, int& rel, int& p0, int& p1, int& p2) {
+  p0 = p1 = p2 = -1;
+  if (y < 0 || y >= g.H) return 0;
+  const int r0 = g.rowoff[y], r1 = g.rowoff[y + 1];
+  if (r0 == r1) return 0;
+  const short2 lo_ = make_short2(-32768, -32768), hi_ = make_short2(32767, 32767);
+  int q = r0 + rel;
+  q = q < r0 ? r0 : (q > r1 ? r1 : q);
+  short2 a = q > r0 ? g.srun[q - 1] : lo_, c = q - 1 > r0 ? g.srun[q - 2] : lo_;
+  const short2 b = q < r1 ? g.srun[q] : hi_;
+  if (!(a.x <= x + 1 && x + 1 < b.x)) {
+    int lo = r0, hi = r1;
+    while (lo < hi) {   // first piece with xs > x + 1
+      const int mid = (lo + hi) >> 1;
+      if (g.srun[mid].x <= x + 1) lo = mid + 1;
+      else hi = mid;
+    }
+    q = lo;
+    a = q > r0 ? g.srun[q - 1] : lo_;
+    c = q - 1 > r0 ? g.srun[q - 2] : lo_;
+  }
+  rel = q - r0;
+  int bits = 0;
+  // only the last two pieces that start at or before x + 1 can reach these columns (touching pieces exist at tile
+  // seams only, 256 columns apart)
+  if (a.x <= x - 1 && x - 1 <= a.y) { bits |= 1; p0 = q - 1; } else if (c.x <= x - 1 && x - 1 <= c.y) { bits |= 1; p0 = q - 2; }
+  if (a.x <= x && x <= a.y) { bits |= 2; p1 = q - 1; } else if (c.x <= x && x <= c.y) { bits |= 2; p1 = q - 2; }
+  if (a.x <= x + 1 && x + 1 <= a.y) { bits |= 4; p2 = q - 1; } else if (c.x <= x + 1 && x + 1 <= c.y) { bits |= 4; p2 = q - 2; }
+  return bits;
+}
+
+// the 8 neighbours of (x, y) as a bit per direction (E NE N NW W SW S SE) and the piece of each
+__device__ __forceinline__ int v1_nbhd(const V1Grid& g, int x, int y, int* rel, int* pc) {
+  int t0, t1, t2, m0, m1, m2, b0, b1, b2;
+  const int top = v1_row3(g, x, y - 1, rel[0], t0, t1, t2);
+  const int mid = v1_row3(g, x, y, rel[1], m0, m1, m2);
+  const int bot = v1_row3(g, x, y + 1, rel[2], b0, b1, b2);
+  pc[0] = m2; pc[1] = t2; pc[2] = t1; pc[3] = t0; pc[4] = m0; pc[5] = b0; pc[6] = b1; pc[7] = b2;
+  return ((mid >> 2) & 1) | ((top >> 2) & 1) << 1 | ((top >> 1) & 1) << 2 | (top & 1) << 3 | (mid & 1) << 4 |
+         (bot & 1) << 5 | ((bot >> 1) & 1) << 6 | ((bot >> 2) & 1) << 7;
+}
+
+// FillConvexPoly's scan fill by a whole wave.  Each of the two edge walkers steps through the vertices in its
+// direction from the top vertex and changes edge whenever its row reaches the current edge's end: its edges are the
+// vertices that lie lower than every vertex before them (a running maximum), each starting at its predecessor's
+// column in the row of the previous such vertex, with a slope fixed there -- so a row's two edge positions follow
+// from a prefix maximum instead of from the rows before it.  The library's budget of n vertex visits for both
+// walkers together ends the fill at the first row where the visits so far exceed n; visits only grow, so a row is
+// painted iff the two edges that cover it were reached within n visits.  `tab`: 6 ints per row (global scratch).
+// Returns false (nothing painted) when the scratch does not fit.
+__device__ bool v1_fill_wave(V1Paint& p, const short2* v, int n, int lane, const V1FastCtx& cx) {
+  const int W = p.g.W, H = p.g.H;
+  int xmin = 0x7fffffff, xmax = -0x7fffffff, ymax = -0x7fffffff, ykey = 0x7fffffff;   // ykey = (y << 16) | index
+  for (int i = lane; i < n; i += 64) {
+    const short2 q = v[i];
+    const int k = ((int)q.y << 16) | i;
+    ykey = k < ykey ? k : ykey;
+    ymax = ymax > q.y ? ymax : q.y;
+    xmax = xmax > q.x ? xmax : q.x;
+    xmin = xmin < q.x ? xmin : q.x;
+  }
+  for (int o = 1; o < 64; o <<= 1) {
+    const int a = __shfl_xor(ykey, o), b = __shfl_xor(ymax, o), c = __shfl_xor(xmax, o), d = __shfl_xor(xmin, o);
+    ykey = a < ykey ? a : ykey;
+    ymax = b > ymax ? b : ymax;
+    xmax = c > xmax ? c : xmax;
+    xmin = d < xmin ? d : xmin;
+  }
+  const int ymin = ykey >> 16, imin = ykey & 0xffff;
+  if (n < 3 || xmax < 0 || ymax < 0 || xmin >= W || ymin >= H || ymax <= ymin) return true;   // nothing to fill
+  const int rows = ymax - ymin;   // rows ymin .. ymax - 1 can be painted
+  int tb = 0;
+  if (lane == 0) tb = v1_bump(cx.s_vused, rows * 6, cx.fast_cap);
+  tb = __shfl(tb, 0);
+  if (tb < 0) return false;
+  int* tab = (int*)(cx.vpool + tb);
+  for (int k = lane; k < rows * 2; k += 64) tab[k * 3 + 2] = 0x7fffffff;   // visits: no edge covers the row
+  v1_wave_sync();
+  const int chunk = (n + 63) / 64;
+  for (int wk = 0; wk < 2; wk++) {
+    const int t0 = 1 + lane * chunk, t1 = t0 + chunk < n + 1 ? t0 + chunk : n + 1;
+    auto idx = [&](int t) {
+      int k = wk == 0 ? imin + t : imin - t + n;
+      return k >= n ? k - n : k;
+    };
+    int mx = -0x7fffffff;
+    for (int t = t0; t < t1; t++) {
+      const int y = v[idx(t)].y;
+      mx = mx > y ? mx : y;
+    }
+    int pm = mx;   // inclusive prefix maximum over the lanes, then the maximum of everything before this lane
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(pm, o);
+      if (lane >= o) pm = pm > u ? pm : u;
+    }
+    pm = __shfl_up(pm, 1);
+    if (lane == 0 || pm < ymin) pm = ymin;
+    if (t0 < t1) {
+      short2 q0 = v[idx(t0 - 1)];
+      for (int t = t0; t < t1; t++) {
+        const short2 q = v[idx(t)];
+        if (q.y > pm) {   // the walker's edge from row pm to row q.y
+          const int dy = q.y - pm;
+          const int dx = (((int)q.x - (int)q0.x) * 131072 + dy) / (2 * dy);   // C division, as the library's
+          const int w0 = (int)(unsigned short)q0.x | pm << 16;
+          for (int y = pm; y < q.y; y++) {
+            int* e = tab + ((y - ymin) * 2 + wk) * 3;
+            e[0] = w0;
+            e[1] = dx;
+            e[2] = t;
+          }
+          pm = q.y;
+        }
+        q0 = q;
+      }
+    }
+  }
+  v1_wave_sync();
+  for (int y = ymin + lane; y < ymax; y += 64) {
+    const int* e = tab + (y - ymin) * 6;
+    const int a0 = v1_gl(e), a1 = v1_gl(e + 1), a2 = v1_gl(e + 2), b0 = v1_gl(e + 3), b1 = v1_gl(e + 4), b2 = v1_gl(e + 5);
+    if (a2 == 0x7fffffff || b2 == 0x7fffffff || a2 + b2 > n) continue;
+    const long long ex0 = ((long long)(a0 & 0xffff) << 16) + (long long)(y - (a0 >> 16)) * a1;
+    const long long ex1 = ((long long)(b0 & 0xffff) << 16) + (long long)(y - (b0 >> 16)) * b1;
+    const long long xl = ex0 > ex1 ? ex1 : ex0, xr = ex0 > ex1 ? ex0 : ex1;
+    const int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
+    if (xx2 >= 0 && xx1 < W) v1_paint_span(p, y, xx1 < 0 ? 0 : xx1, xx2 >= W ? W - 1 : xx2);
+  }
+  p.cur = v1_gmax<64>(p.cur);
+  return true;
+}
+
+// One wave (all 64 lanes, uniform arguments).  `i` = the blob's number = its outer border's contour, `me` = its root
+// piece, rows y_first .. y_last.  True: every border loop of the blob is in the contour tables, filled, with its
+// arg-max key; false: nothing was changed.
+__device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, int i, int me, int y_first, int y_last,
+                             int lane) {
+  const int* rowoff = g.rowoff;
+  const short2* srun = g.srun;
+  [[maybe_unused]] const long long t0_ = V1B_NOW();
+  // (1) the blob's pieces, a lane per row
+  int np = 0;
+  for (int yb = y_first; yb <= y_last; yb += 64) {
+    const int y = yb + lane;
+    int c = 0;
+    if (y <= y_last)
+      for (int j = rowoff[y]; j < rowoff[y + 1]; j++) c += cx.parent[j] == me;
+    np += __shfl(v1_wave_incl_scan(c, lane), 63);
+  }
+  if (np < 1 || np > 5000) return false;   // (16-bit vertex sums: at most V1F_K per node)
+  if (lane == 0) V1B_ADD(23, np);
+  const int nn = 2 * np;
+  int* ltab = cx.ltab;
+  // (2) tables: the pointer-jumping words in LDS when the block has 16 B per piece left, everything else (and those
+  // words otherwise) in the vertex pool
+  int a = 0, tb = 0;
+  if (lane == 0) {
+    a = v1_bump(cx.s_free, 8 * nn, cx.lds_limit);
+    tb = v1_bump(cx.s_vused, (a < 0 ? V1F_UNITS : V1F_UNITS - 4) * np, cx.fast_cap);
+  }
+  a = __shfl(a, 0);
+  tb = __shfl(tb, 0);
+  if (tb < 0) {
+    if (lane == 0) V1B_ADD(17, 1);
+    return false;
+  }
+  unsigned short* succ = (unsigned short*)(cx.vpool + tb);          // nn: the next node of the border loop
+  unsigned short* st = succ + nn;                                   // nn: predecessor, then first node of the loop
+  unsigned short* plist = st + nn;                                  // np: sorted position of the piece
+  unsigned short* prow = plist + np;                                // np: its row
+  unsigned char* cntfl = (unsigned char*)(prow + np);               // nn: vertices | 0x40 sweeps east | 0x80 node
+  unsigned char* loop = cntfl + nn;                                 // nn: (first nodes only) number of the loop
+  short2* tmp = (short2*)(loop + nn);                               // nn x V1F_K: a segment's vertices
+  // nn words, 8-byte aligned (the tables above take 4 + 2 K entries per piece, these 4, the rounding at most 1)
+  unsigned long long* jwg = (unsigned long long*)(cx.vpool + ((tb + (4 + 2 * V1F_K) * np + 1) & ~1));
+  const bool jl = a >= 0;
+  auto jw_ld = [&](int k) -> unsigned long long {
+    return jl ? ((const unsigned long long*)(cx.lds + a))[k] : v1_gl(jwg + k);
+  };
+  auto jw_st = [&](int k, unsigned long long w) {
+    if (jl) ((unsigned long long*)(cx.lds + a))[k] = w;
+    else jwg[k] = w;
+  };
+  {
+    int base = 0;
+    for (int yb = y_first; yb <= y_last; yb += 64) {
+      const int y = yb + lane;
+      int c = 0;
+      if (y <= y_last)
+        for (int j = rowoff[y]; j < rowoff[y + 1]; j++) c += cx.parent[j] == me;
+      const int incl = v1_wave_incl_scan(c, lane);
+      int pos = base + incl - c;
+      if (y <= y_last)
+        for (int j = rowoff[y]; j < rowoff[y + 1]; j++)
+          if (cx.parent[j] == me) {
+            plist[pos] = (unsigned short)j;
+            prow[pos] = (unsigned short)y;
+            cx.mark[j] = (unsigned short)(pos + 1);   // (for the moment: the piece's place in the list)
+            pos++;
+          }
+      base += __shfl(incl, 63);
+    }
+  }
+  v1_wave_sync();
+  [[maybe_unused]] const long long t1_ = V1B_NOW();
+  // (3) a lane per node: its segment
+  int bad = 0;
+  for (int m = lane; m < nn; m += 64) {
+    const int j = v1_gl(plist + (m >> 1)), side = m & 1, y = v1_gl(prow + (m >> 1));
+    const short2 q = srun[j];
+    int cf = 0, nxt = 0xffff;
+    const bool crack = !(side == 0 ? (j > rowoff[y] && srun[j - 1].y + 1 == q.x)
+                                   : (j + 1 < rowoff[y + 1] && srun[j + 1].x == q.y + 1));   // not cut at a tile seam
+    if (crack) {
+      int px = side ? q.y : q.x, py = y;
+      int rel[3] = {0, 0, 0}, pc[8];
+      int nb = v1_nbhd(g, px, py, rel, pc);
+      const int d0 = side ? 0 : 4;
+      // clockwise from the crack: the pixel the walk comes from; a crack whose search passes the pixel's other side
+      // (empty too) is swept by the step that starts there
+      int tcw = 8;
+      for (int t = 7; t >= 1; t--)
+        if (nb >> ((d0 - t) & 7) & 1) tcw = t;
+      if (tcw == 8) bad = 1;   // a single pixel
+      else if (tcw <= 4) {
+        int back = (d0 - tcw) & 7, cnt = 0, j3 = j;
+        cf = 0x80;
+        nxt = -1;
+        for (int step = 0; step < V1F_STEPS; step++) {
+          if (step) nb = v1_nbhd(g, px, py, rel, pc);
+          const int sh = (back + 1) & 7;
+          const int rot = ((nb >> sh) | (nb << (8 - sh))) & 0xff;
+          const int z = __ffs(rot) - 1;              // empty neighbours swept before the first set one
+          if (z < 0) break;                          // (cannot happen: the way back is set)
+          const int sp = (sh + z) & 7;
+          const int dw = (4 - sh) & 7, de = (0 - sh) & 7;
+          const bool sw = dw < z, se = de < z;
+          if (step > 0 && (sw || se)) {
+            nxt = 2 * ((int)cx.mark[j3] - 1) + ((sw && (!se || dw < de)) ? 0 : 1);
+            break;
+          }
+          if (step == 0 && se) cf |= 0x40;
+          const bool turn = sp != (back ^ 4);
+          if (turn) {
+            if (cnt == V1F_K) break;
+            tmp[m * V1F_K + cnt] = make_short2((short)px, (short)py);
+            cnt++;
+          }
+          px += v1_dx(sp);
+          py += v1_dy(sp);
+          j3 = pc[sp];
+          back = sp ^ 4;
+          const int dyv = v1_dy(sp);
+          if (dyv > 0) { rel[0] = rel[1]; rel[1] = rel[2]; } else if (dyv < 0) { rel[2] = rel[1]; rel[1] = rel[0]; }
+          if (!turn && sp == 4) {
+            // second step west in a row: along the top of a run.  Up to the run's first pixel, or to the pixel
+            // below-right of the nearest mask pixel of the row above, every step is the same (west, nothing emitted,
+            // no side swept)
+            int qe = -32768;
+            if (py > 0) {
+              const int r0 = rowoff[py - 1];
+              int lo = r0, hi = rowoff[py];
+              while (lo < hi) {   // first piece with xs > px + 1
+                const int mid = (lo + hi) >> 1;
+                if (srun[mid].x <= px + 1) lo = mid + 1;
+                else hi = mid;
+              }
+              if (lo > r0) qe = srun[lo - 1].y;
+            }
+            const int xs3 = srun[j3].x, xt = qe + 1 > xs3 ? qe + 1 : xs3;
+            if (xt < px) px = xt;
+          } else if (!turn && sp == 0) {
+            // the same eastwards along the bottom of a run
+            int qs = 32767;
+            if (py + 1 < g.H) {
+              const int r1 = rowoff[py + 2];
+              int lo = rowoff[py + 1], hi = r1;
+              while (lo < hi) {   // first piece with xe >= px - 1
+                const int mid = (lo + hi) >> 1;
+                if (srun[mid].y < px - 1) lo = mid + 1;
+                else hi = mid;
+              }
+              if (lo < r1) qs = srun[lo].x;
+            }
+            const int xe3 = srun[j3].y, xt = qs - 1 < xe3 ? qs - 1 : xe3;
+            if (xt > px) px = xt;
+          }
+        }
+        if (nxt < 0) {
+          bad = 1;
+          nxt = 0xffff;
+        }
+        cf |= cnt;
+      }
+    }
+    succ[m] = (unsigned short)nxt;
+    cntfl[m] = (unsigned char)cf;
+    st[m] = 0xffff;
+    loop[m] = 0xff;
+  }
+  v1_wave_sync();
+  [[maybe_unused]] const long long t2_ = V1B_NOW();
+  // (4) the loops = the cycles of succ[].  First: succ[] must be a permutation of the nodes (every successor a node,
+  // no two nodes with the same one)
+  int nvert = 0;
+  for (int m = lane; m < nn; m += 64) {
+    const int cf = cntfl[m];
+    if (!(cf & 0x80)) continue;
+    const int nx = succ[m];
+    if (nx >= nn || !(v1_gl(cntfl + nx) & 0x80)) bad = 1;
+    else st[nx] = (unsigned short)m;
+    nvert += cf & 0x3f;
+  }
+  v1_wave_sync();
+  for (int m = lane; m < nn; m += 64)
+    if ((cntfl[m] & 0x80) && !bad && v1_gl(st + succ[m]) != m) bad = 1;
+  for (int o = 32; o; o >>= 1) nvert += __shfl_xor(nvert, o);
+  const int ms = (v1_gl(cntfl) & 0x80) ? 0 : 1;   // the outer border starts at the first pixel's west crack
+  if (nvert > 65535 || !(v1_gl(cntfl + ms) & 0x80)) bad = 1;
+  bad = __any(bad);
+  int nl = 1, total = 0, fbase = 0, cbase = 0;
+  if (!bad) {
+    // pointer jumping on {next node, key, vertices to the key's node, vertices of the window}: key = 0 for the outer
+    // border's first node, 1 + piece for a node that sweeps an east crack (pieces are in raster order): after
+    // log2(nodes) doublings every node knows its loop's first node -- the library starts a hole border at its first
+    // east crack in raster order -- and the vertices emitted from itself up to there.  Updated in place: any mix of
+    // old and new words is a valid pair of windows.
+    for (int m = lane; m < nn; m += 64) {
+      const int cf = cntfl[m];
+      unsigned long long w = (unsigned long long)m | 0xffffull << 16;
+      if (cf & 0x80) {
+        const unsigned key = m == ms ? 0u : ((cf & 0x40) ? (unsigned)(m >> 1) + 1u : 0xffffu);
+        w = (unsigned long long)succ[m] | (unsigned long long)key << 16 | (unsigned long long)(cf & 0x3f) << 48;
+      }
+      jw_st(m, w);
+    }
+    v1_wave_sync();
+    int rounds = 1;
+    while ((1 << rounds) < nn) rounds++;
+    for (int k = 0; k < rounds; k++) {
+      for (int mb = lane; mb < nn; mb += 256) {
+        unsigned long long w[4], w2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = mb + 64 * u < nn ? jw_ld(mb + 64 * u) : 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; u++) w2[u] = jw_ld((int)(w[u] & 0xffff));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (mb + 64 * u >= nn) continue;
+          const unsigned ka = (unsigned)(w[u] >> 16) & 0xffff, kb = (unsigned)(w2[u] >> 16) & 0xffff;
+          const unsigned sa = (unsigned)(w[u] >> 48), sb = (unsigned)(w2[u] >> 48);
+          const unsigned da = (unsigned)(w[u] >> 32) & 0xffff, db = (unsigned)(w2[u] >> 32) & 0xffff;
+          const unsigned key = kb < ka ? kb : ka, dist = kb < ka ? (sa + db) & 0xffff : da;
+          jw_st(mb + 64 * u, (w2[u] & 0xffff) | (unsigned long long)key << 16 | (unsigned long long)dist << 32 |
+                                 (unsigned long long)((sa + sb) & 0xffff) << 48);
+        }
+      }
+      v1_wave_sync();
+    }
+    // the loop's first node
+    for (int m = lane; m < nn; m += 64) {
+      if (!(cntfl[m] & 0x80)) continue;
+      const unsigned key = (unsigned)(jw_ld(m) >> 16) & 0xffff;
+      int s0 = ms;
+      if (key == 0xffff) bad = 1;
+      else if (key) s0 = (v1_gl(cntfl + 2 * (key - 1) + 1) & 0x80) ? 2 * (key - 1) + 1 : 2 * (key - 1);
+      st[m] = (unsigned short)s0;
+    }
+    v1_wave_sync();
+    // number the loops (0 = outer, holes in node order), their vertex counts
+    for (int mb = 0; mb < nn; mb += 64) {
+      const int m = mb + lane;
+      const bool first = m < nn && (cntfl[m] & 0x80) && st[m] == m;
+      const bool hole = first && m != ms;
+      const unsigned long long bal = __ballot(hole);
+      if (first) {
+        const int no = hole ? nl + __popcll(bal & ((1ull << lane) - 1ull)) : 0;
+        const unsigned long long w = jw_ld(m);
+        const int nx = succ[m];
+        if ((w >> 32) & 0xffff) bad = 1;   // (the first node is the key's node: no vertices before it)
+        if (no < V1F_LOOPS) {
+          loop[m] = (unsigned char)no;
+          ltab[no * 4] = (cntfl[m] & 0x3f) + (nx == m ? 0 : (int)((jw_ld(nx) >> 32) & 0xffff));
+          ltab[no * 4 + 1] = (int)((w >> 16) & 0xffff) - 1;
+        }
+      }
+      nl += __popcll(bal);
+    }
+    if (nl > V1F_LOOPS) bad = 1;
+    bad = __any(bad);
+  }
+  if (!bad) {
+    v1_wave_sync();
+    const int T = lane < nl ? ltab[lane * 4] : 0;
+    const int incl = v1_wave_incl_scan(T, lane);
+    if (lane < nl) ltab[lane * 4 + 2] = incl - T;
+    total = __shfl(incl, 63);
+    if ((lane < nl && T < 1) || total != nvert) bad = 1;
+    bad = __any(bad);
+  }
+  if (!bad) {
+    if (lane == 0) {
+      fbase = v1_bump(cx.s_vused, total, cx.fast_cap);
+      if (fbase >= 0 && nl > 1) cbase = atomicAdd(cx.s_ncont, nl - 1);
+    }
+    fbase = __shfl(fbase, 0);
+    cbase = __shfl(cbase, 0);
+    if (fbase < 0) bad = 1;
+    else if (nl > 1 && cbase + nl - 1 > cx.kp_cap) {
+      // the contour table is full: the result is flagged, the entries taken below the cap only have to be harmless
+      for (int c = cbase + lane; c < cx.kp_cap; c += 64) {
+        cx.c_disc[c] = 0;
+        cx.c_par[c] = (short)i;
+        cx.c_link[c] = -1;
+        cx.c_hole[c] = 1;
+        cx.c_key[c] = 0ull;
+      }
+      if (lane == 0) *cx.overflow = 1;
+      for (int k = lane; k < np; k += 64) cx.mark[v1_gl(plist + k)] = 0;
+      v1_wave_sync();
+      return true;
+    }
+  }
+  if (bad) {
+    for (int k = lane; k < np; k += 64) cx.mark[v1_gl(plist + k)] = 0;
+    v1_wave_sync();
+    if (lane == 0) V1B_ADD(18, 1);
+    return false;
+  }
+  v1_wave_sync();
+  [[maybe_unused]] const long long t3_ = V1B_NOW();
+  // (5) vertices to their places (a lane reads back what it wrote itself), marks, contour entries
+  for (int m = lane; m < nn; m += 64) {
+    const int cf = cntfl[m];
+    if (!(cf & 0x80)) continue;
+    const int s0 = st[m], l = v1_gl(loop + s0);
+    const int first = m == s0 ? 0 : ltab[l * 4] - (int)((jw_ld(m) >> 32) & 0xffff);
+    short2* dst = cx.vpool + fbase + ltab[l * 4 + 2] + first;
+    for (int k = 0; k < (cf & 0x3f); k++) dst[k] = tmp[m * V1F_K + k];
+  }
+  for (int k = lane; k < np; k += 64) {
+    const int e = v1_gl(cntfl + 2 * k + 1), w = v1_gl(cntfl + 2 * k);
+    int l = -1;
+    if (e & 0x80) l = v1_gl(loop + v1_gl(st + 2 * k + 1));
+    else if ((w & 0xc0) == 0xc0) l = v1_gl(loop + v1_gl(st + 2 * k));
+    cx.mark[v1_gl(plist + k)] = (unsigned short)(l < 0 ? 0 : (l == 0 ? i : cbase + l - 1) + 1);
+  }
+  for (int l = 1 + lane; l < nl; l += 64) {
+    const int c = cbase + l - 1, k = ltab[l * 4 + 1];
+    cx.c_disc[c] = (int)v1_gl(prow + k) * cx.W + srun[v1_gl(plist + k)].y;
+    cx.c_par[c] = (short)i;
+    cx.c_link[c] = -1;
+    cx.c_hole[c] = 1;
+    cx.c_key[c] = 0ull;
+  }
+  v1_wave_sync();
+  [[maybe_unused]] const long long t4_ = V1B_NOW();
+  // (6) the fills, the whole wave on one loop after the other
+  for (int l = 0; l < nl; l++) {
+    const short2* v = cx.vpool + fbase + ltab[l * 4 + 2];
+    const int n = ltab[l * 4];
+    pt.cur = 0ull;
+    if (v1_fill_wave(pt, v, n, lane, cx)) v1_fill_paint<64, false>(pt, v, n, lane);
+    else v1_fill_paint<64, true>(pt, v, n, lane);
+    if (lane == 0) cx.c_key[l == 0 ? i : cbase + l - 1] = pt.cur;
+  }
+  if (lane == 0) {
+    V1B_ADD(16, 1);
+    V1B_ADD(19, t1_ - t0_);
+    V1B_ADD(20, t2_ - t1_);
+    V1B_ADD(21, t3_ - t2_);
+    V1B_ADD(22, t4_ - t3_);
+    V1B_ADD(24, V1B_NOW() - t4_);
+    V1B_ADD(25, nl);
+    V1B_ADD(26, total);
+  }
+  return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -932,7 +1496,7 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
                                                        const int* __restrict__ n_runs, const V1Run* __restrict__ runs,
                                                        short2* __restrict__ ws_verts,
                                                        float* __restrict__ kps, int* __restrict__ n_kps,
-                                                       int* __restrict__ overflow) {
+                                                       int* __restrict__ overflow, int lds_bytes, int fast) {
   extern __shared__ __attribute__((aligned(16))) int ismem[];
   const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const long long tb0_ = V1B_NOW();
@@ -947,22 +1511,25 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
   }
   const V1Run* R = runs + ((size_t)b * n_parts + part) * run_cap;
   short2* vpool = ws_verts + ((size_t)b * n_parts + part) * vert_cap;
-  // LDS: the mask as pieces sorted by (row, xs); every table below is indexed by sorted position
-  int* parent = ismem;                                          // run_cap: union-find, then each piece's blob root
-  int* rowoff = parent + run_cap;                               // H + 2
+  // LDS: the mask as pieces sorted by (row, xs); every table below is indexed by sorted position.  The tables are
+  // laid out for the n pieces this plane has, not for run_cap: what is left of the block's LDS (sized for run_cap by
+  // the launcher) is the fast walk's table space
+  const int nn = (n + 3) & ~3;
+  int* parent = ismem;                                          // n: union-find, then each piece's blob root
+  int* rowoff = parent + nn;                                    // H + 2
   int* roots = rowoff + H + 2;                                  // kp_cap: the blobs' root pieces
-  float* bval = (float*)(roots + kp_cap);                       // run_cap: the piece's maximum
-  short2* srun = (short2*)(bval + run_cap);                     // run_cap: {xs, xe}
-  unsigned short* byrow = (unsigned short*)(srun + run_cap);    // run_cap: index in R
-  unsigned short* mark = byrow + run_cap;                       // run_cap: contour id + 1 of the trace that last
-                                                                //          right-marked the piece's last pixel
+  float* bval = (float*)(roots + kp_cap);                       // n: the piece's maximum
+  short2* srun = (short2*)(bval + nn);                          // n: {xs, xe}
+  unsigned short* byrow = (unsigned short*)(srun + nn);         // n: index in R
+  unsigned short* mark = byrow + nn;                            // n: contour id + 1 of the trace that
+                                                                //    right-marked the piece's last pixel
   // (offsets from the LDS base, not integer casts of pointers: the tables then stay LDS pointers for the compiler --
   // through a cast they became generic ones, read with flat loads at about twice the latency)
   auto up = [&](const void* p_, size_t a) {
     const size_t off = (size_t)((const char*)p_ - (const char*)ismem);
     return (char*)ismem + ((off + a - 1) & ~(a - 1));
   };
-  unsigned long long* c_key = (unsigned long long*)up(mark + run_cap, 8);  // per contour: arg-max key
+  unsigned long long* c_key = (unsigned long long*)up(mark + nn, 8);  // per contour: arg-max key
   int* c_disc = (int*)(c_key + kp_cap);          // discovery position (raster index of the border's start)
   short* c_par = (short*)(c_disc + kp_cap);      // parent contour, -1 = the frame
   short* c_link = c_par + kp_cap;                // outer borders: the border met last before their first pixel
@@ -974,14 +1541,16 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
   int* b_first = (int*)(b_best + kp_cap);
   int* b_ymax = b_first + kp_cap;
   int* b_nrun = b_ymax + kp_cap;
-  __shared__ int s_nroot, s_nirr, s_ncont, s_vused;
+  __shared__ int s_nroot, s_nirr, s_ncont, s_vused, s_free;
   __shared__ int s_wsum[V1B_THREADS / 64];
+  __shared__ int s_ltab[V1B_THREADS / 64][V1F_LOOPS * 4];
 
   for (int i = tid; i < H + 2; i += V1B_THREADS) rowoff[i] = 0;
   if (tid == 0) {
     s_nroot = 0;
     s_nirr = 0;
     s_vused = 0;
+    s_free = (int)((const char*)up(b_nrun + kp_cap, 16) - (const char*)ismem);
   }
   __syncthreads();
   for (int i = tid; i < n; i += V1B_THREADS) {
@@ -1108,6 +1677,21 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
   }
   __syncthreads();
   const int nirr = s_nirr;
+  if (nirr > 1) {
+    // the largest blobs first: they are the kernel's critical path, and the first to come get the fast walk's tables
+    for (int t = tid; t < nirr; t += V1B_THREADS) {
+      const int it = irr[t], kt = b_nrun[it];
+      int rank = 0;
+      for (int u = 0; u < nirr; u++) {
+        const int ku = b_nrun[irr[u]];
+        rank += ku > kt || (ku == kt && u < t);
+      }
+      c_depth[rank] = (short)it;
+    }
+    __syncthreads();
+    for (int t = tid; t < nirr; t += V1B_THREADS) irr[t] = (unsigned short)c_depth[t];
+    __syncthreads();
+  }
   [[maybe_unused]] const long long tw0_ = V1B_NOW();
   if (tid == 0) {
     V1B_ADD(7, tw0_ - tb0_);
@@ -1123,8 +1707,27 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
     // one group of 8 lanes per blob.  Groups of one wave that walk different blobs run one after the other (their
     // control flow differs), so consecutive blobs go to different WAVES first: blob k -> wave k % NW, group k / NW % 8
     constexpr int NW = V1B_THREADS / 64;
+    // first a WAVE per blob: all its border loops at once (v1_fast_blob); the blobs that leaves (bit 15 of their
+    // entry) go through the one-group walk below
+    {
+      const V1FastCtx cx = {parent, mark, (char*)ismem, &s_free, lds_bytes, vpool, &s_vused, vert_cap,
+                            vert_cap - 8 * run_cap, s_ltab[tid >> 6], W, kp_cap,
+                            &s_ncont, c_disc, c_par, c_link, c_hole, c_key, overflow};
+      for (int k = tid >> 6; k < nirr; k += NW) {
+        const int i = irr[k];
+        const int fp = c_disc[i];
+        [[maybe_unused]] const long long ta_ = V1B_NOW();
+        const bool done = fast && v1_fast_blob(g, pt, cx, i, roots[i], fp / W, b_ymax[i], lane);
+        if (lane == 0) {
+          if (!done) irr[k] = (unsigned short)(i | 0x8000);
+          V1B_ADD(2, V1B_NOW() - ta_);
+        }
+      }
+    }
+    __syncthreads();
     for (int k = ((tid >> 3) & 7) * NW + (tid >> 6); k < nirr; k += 8 * NW) {
-      const int i = irr[k], me = roots[i];
+      if (!(irr[k] & 0x8000)) continue;
+      const int i = irr[k] & 0x7fff, me = roots[i];
       const int fp = c_disc[i], y_first = fp / W, y_last = b_ymax[i];
       int c = i, sx = fp - y_first * W, sy = y_first;   // the outer border starts at the blob's first raster pixel
       bool hole = false;
@@ -1137,7 +1740,7 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
         }
         [[maybe_unused]] const long long tb_ = V1B_NOW();
         pt.cur = 0ull;
-        v1_fill_paint(pt, vpool + vv.base, nv, lane);
+        v1_fill_paint<8>(pt, vpool + vv.base, nv, lane);
         if (r == 0) c_key[c] = pt.cur;
         [[maybe_unused]] const long long tc_ = V1B_NOW();
         if (r == 0) {
@@ -1481,7 +2084,7 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   const size_t ldsA = ((size_t)hs * ws + (size_t)(V1_TILE_H + 2) * (V1_TILE_W + 2) +
                        (size_t)(V1_TILE_H + 2) * V1_TILE_W + (size_t)V1_TILE_H * V1_TILE_W) * 4;
   // K-B: the sorted pieces (root, maximum, extents, run index, mark), row offsets, blob and contour tables
-  const size_t ldsB = (size_t)c.run_cap * (4 + 4 + 4 + 2 + 2) + ((size_t)H + 2 + c.kp_cap) * 4 + 8 +
+  const size_t ldsB = (size_t)((c.run_cap + 3) & ~3) * (4 + 4 + 4 + 2 + 2) + ((size_t)H + 2 + c.kp_cap) * 4 + 8 +
                       (size_t)c.kp_cap * (8 + 4 + 2 + 2 + 2 + 2 + 1) + 16 + (size_t)c.kp_cap * (8 + 4 + 4 + 4) + 8;
   const size_t ldsC = (size_t)2 * hs * ws * 4;
   const size_t ldsD = (size_t)c.person_cap * (m.n_parts + 1) * 8;
@@ -1508,6 +2111,8 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   const int tiles = ((W + V1_TILE_W - 1) / V1_TILE_W) * ((H + V1_TILE_H - 1) / V1_TILE_H);
   if (ev) PH_CHECK(hipEventRecord(ev[0], stream));
   static const bool tiled_runs = [] { const char* e = getenv("POSEHIP_V1_RUNS"); return e && e[0] == '0'; }();
+  const char* fe = getenv("POSEHIP_V1_FAST");   // "0": every irregular blob through the one-group walk (read per call: A/B tests)
+  const bool no_fast = fe && fe[0] == '0';
   if (tiled_runs) {
     hipLaunchKernelGGL(v1_runs_kernel, dim3(tiles, m.n_parts, B), dim3(V1_RUN_THREADS), ldsA, stream, net_out, C, hs, ws, W, H,
                        thr, m.n_parts, c.run_cap, w.n_runs, w.runs, w.overflow);
@@ -1523,7 +2128,7 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   if (ev) PH_CHECK(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(v1_blobs_kernel, dim3(m.n_parts, B), dim3(V1B_THREADS), ldsB, stream, net_out, C, hs, ws, W, H, m.n_parts,
                      c.run_cap, c.kp_cap, V1_VERT_POOL(c.run_cap), (const int*)w.n_runs, (const V1Run*)w.runs,
-                     w.ws_verts, w.kps, w.n_kps, w.overflow);
+                     w.ws_verts, w.kps, w.n_kps, w.overflow, (int)ldsB, no_fast ? 0 : 1);
   if (ev) PH_CHECK(hipEventRecord(ev[2], stream));
   hipLaunchKernelGGL(v1_pairs_kernel, dim3(m.n_limbs, B), dim3(256), ldsC, stream, net_out, C, hs, ws, W, H, m,
                      c.kp_cap, (const float*)w.kps, (const int*)w.n_kps, w.pairs, w.n_pairs);

@@ -15,7 +15,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 eng = Engine(0)
 bp, pp = get_body_parts_and_pose_pairs("COCO")
 eng.set_net_out(np.stack([synth.synth_net_output(2000 * P + i, P, COCO_18, 46, 82) for i in range(B)]))
-L = _ffi.lib(); cyc = (ctypes.c_ulonglong * 16)()
+L = _ffi.lib(); cyc = (ctypes.c_ulonglong * 32)()
 for _ in range(3):
     eng.decode_v1(bp, pp, MAPIDX, B, 1920, 1080, 0.1, kp_cap=256, person_cap=1024)
 if not hasattr(L, "ph_debug_v1_blobs"):      # a build without the stamps: kernel times only (median of 9)
@@ -39,3 +39,8 @@ print(f"per contour (one group of 8 lanes): trace {cyc[0] / nc:.0f} cycles, fill
 print(f"pixel-by-pixel re-evaluation: {cyc[4]} spans, {cyc[3]} pixels ({cyc[3] / nb:.0f} per block)")
 print(f"trace steps per contour {cyc[13] / nc:.0f} ({cyc[0] / max(1, cyc[13]):.0f} cycles per step); fill rows per contour "
       f"{cyc[14] / nc:.0f}; outline {cyc[15] / nc:.0f} cycles per contour")
+nf = max(1, cyc[16])
+print(f"fast path: {cyc[16]} blobs done, {cyc[17]} without table space, {cyc[18]} given back; per blob: pieces "
+      f"{cyc[23] / max(1, cyc[16] + cyc[17] + cyc[18]):.0f}, loops {cyc[25] / nf:.2f}, vertices {cyc[26] / nf:.0f}; cycles: piece list "
+      f"{cyc[19] / nf:.0f}, segments {cyc[20] / nf:.0f}, loop walk {cyc[21] / nf:.0f}, placement {cyc[22] / nf:.0f}, "
+      f"fills {cyc[24] / nf:.0f}; whole call (all blobs) {cyc[2] / max(1, cyc[5]):.0f}")
