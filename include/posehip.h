@@ -267,6 +267,11 @@ int ph_decode_v1(ph_ctx* ctx, const ph_v1_model* model, int B, int W0, int H0, f
                  double* persons);
 /* device time (ms) of the last ph_decode_v1: [0] resize+blur+runs, [1] blobs, [2] pairs+assembly */
 int ph_decode_v1_times(ph_ctx* ctx, float* ms3);
+/* of the last ph_decode_v1 (no reference counterpart; for tests and profiles): how many blobs with several runs in
+ * a row -- the ones that need the literal findContours / fillConvexPoly of utils.py:14-22 -- were walked by a whole
+ * wave (all border loops at once) and how many by the one-group walk (POSEHIP_V1_FAST=0, or a guard of the wave
+ * walk tripped). */
+int ph_decode_v1_walks(ph_ctx* ctx, int32_t* wave, int32_t* group);
 
 #ifdef __cplusplus
 }

@@ -125,6 +125,7 @@ struct ph_ctx {
   V1Buffers v1 = {};
   V1Sizes v1sz = {};
   size_t v1_key = 0;
+  int v1_walks[2] = {0, 0};   // of the last ph_decode_v1: irregular blobs walked by a wave / by one group
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev1[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> op_ev;
@@ -1279,7 +1280,7 @@ int ph_decode_v1(ph_ctx* c, const ph_v1_model* m, int B, int W0, int H0, float c
     PH_CHECK(hipMalloc(&c->v1.n_pairs, c->v1sz.n_pairs));
     PH_CHECK(hipMalloc(&c->v1.persons, c->v1sz.persons));
     PH_CHECK(hipMalloc(&c->v1.n_persons, c->v1sz.n_persons));
-    PH_CHECK(hipMalloc(&c->v1.overflow, sizeof(int)));
+    PH_CHECK(hipMalloc(&c->v1.overflow, 4 * sizeof(int)));   // flag, blobs walked by a wave, by one group, -
     c->v1_key = key;
   }
   if (ph_launch_decode_v1(c->cur_out, c->cur_c, c->cur_h, c->cur_w, W0, H0, conf_thres, dev, B, caps, c->v1,
@@ -1292,9 +1293,12 @@ int ph_decode_v1(ph_ctx* c, const ph_v1_model* m, int B, int W0, int H0, float c
   if (pairs) PH_CHECK(hipMemcpyAsync(pairs, c->v1.pairs, c->v1sz.pairs, hipMemcpyDeviceToHost, s));
   if (n_persons) PH_CHECK(hipMemcpyAsync(n_persons, c->v1.n_persons, c->v1sz.n_persons, hipMemcpyDeviceToHost, s));
   if (persons) PH_CHECK(hipMemcpyAsync(persons, c->v1.persons, c->v1sz.persons, hipMemcpyDeviceToHost, s));
-  int overflow = 0;
-  PH_CHECK(hipMemcpyAsync(&overflow, c->v1.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+  int flags[4] = {0, 0, 0, 0};
+  PH_CHECK(hipMemcpyAsync(flags, c->v1.overflow, sizeof(flags), hipMemcpyDeviceToHost, s));
   PH_CHECK(hipStreamSynchronize(s));
+  const int overflow = flags[0];
+  c->v1_walks[0] = flags[1];
+  c->v1_walks[1] = flags[2];
   if (overflow) {
     ph_set_error("ph_decode_v1: capacity exceeded (more than %d mask runs or %d contours per part, the contour vertex pool, or %d people)",
                  caps.run_cap, kp_cap, person_cap);
@@ -1306,6 +1310,12 @@ int ph_decode_v1(ph_ctx* c, const ph_v1_model* m, int B, int W0, int H0, float c
 int ph_decode_v1_times(ph_ctx* c, float* ms3) {
   PH_CHECK(hipStreamSynchronize(c->stream));
   for (int i = 0; i < 3; i++) PH_CHECK(hipEventElapsedTime(&ms3[i], c->ev1[i], c->ev1[i + 1]));
+  return 0;
+}
+
+int ph_decode_v1_walks(ph_ctx* c, int32_t* wave, int32_t* group) {
+  if (wave) *wave = c->v1_walks[0];
+  if (group) *group = c->v1_walks[1];
   return 0;
 }
 

@@ -1720,6 +1720,7 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
         const bool done = fast && v1_fast_blob(g, pt, cx, i, roots[i], fp / W, b_ymax[i], lane);
         if (lane == 0) {
           if (!done) irr[k] = (unsigned short)(i | 0x8000);
+          atomicAdd(overflow + (done ? 1 : 2), 1);
           V1B_ADD(2, V1B_NOW() - ta_);
         }
       }
@@ -2106,7 +2107,7 @@ int ph_launch_decode_v1(const float* net_out, int C, int hs, int ws, int W, int 
   V1Sizes sz;
   ph_v1_sizes(m, B, W, H, c, &sz);
   PH_CHECK(hipMemsetAsync(w.n_runs, 0, sz.n_runs, stream));
-  PH_CHECK(hipMemsetAsync(w.overflow, 0, sizeof(int), stream));
+  PH_CHECK(hipMemsetAsync(w.overflow, 0, 4 * sizeof(int), stream));   // flag + the two walk counters
   PH_CHECK(hipMemsetAsync(w.kps, 0, sz.kps, stream));
   const int tiles = ((W + V1_TILE_W - 1) / V1_TILE_W) * ((H + V1_TILE_H - 1) / V1_TILE_H);
   if (ev) PH_CHECK(hipEventRecord(ev[0], stream));

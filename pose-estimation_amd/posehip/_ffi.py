@@ -103,6 +103,7 @@ SYMBOLS = {
     "ph_decode_v1": (C.c_int, [_vp, C.POINTER(PhV1Model), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                _vp, _vp, _vp, _vp, _vp, _vp]),
     "ph_decode_v1_times": (C.c_int, [_vp, _fp]),
+    "ph_decode_v1_walks": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ph_decode_v2_times": (C.c_int, [_vp, _fp]),
 }
 

@@ -324,6 +324,12 @@ class Engine:
         _ffi.check(self._lib.ph_decode_v1_times(self._ctx, ms), "ph_decode_v1_times")
         return list(ms)
 
+    def decode_v1_walks(self):
+        """(blobs walked by a wave, blobs walked by one group) of the last decode_v1."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        _ffi.check(self._lib.ph_decode_v1_walks(self._ctx, C.byref(a), C.byref(b)), "ph_decode_v1_walks")
+        return a.value, b.value
+
     def decode_v2_times(self):
         ms = (C.c_float * 3)()
         _ffi.check(self._lib.ph_decode_v2_times(self._ctx, ms), "ph_decode_v2_times")

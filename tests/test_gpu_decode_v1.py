@@ -49,6 +49,9 @@ def test_decode_v1_matches_oracle(engine, hs, ws, W, H, people):
     pred = synth.synth_net_output(40 + people, people, COCO_18, hs, ws)[None]
     engine.set_net_out(pred)
     got = engine.decode_v1(BODY_PARTS, POSE_PAIRS, MAPIDX, 1, W, H, 0.1)
+    if people == 20:
+        wave, group = engine.decode_v1_walks()
+        assert wave > 0 and group == 0
     ref = _oracle(pred, W, H)
     _check(got[0], ref)
     if people:
@@ -80,6 +83,25 @@ def test_blob_edge_cases(engine):
     assert ref[0].shape[0] >= 4
 
 
+@pytest.fixture(params=["wave", "group"])
+def blob_walk(request, monkeypatch):
+    """Both walks of the blobs that need the literal contour + fill: a whole wave per blob (default) and the
+    one-group border following it falls back to (POSEHIP_V1_FAST=0, read at every call)."""
+    if request.param == "group":
+        monkeypatch.setenv("POSEHIP_V1_FAST", "0")
+    else:
+        monkeypatch.delenv("POSEHIP_V1_FAST", raising=False)
+    return request.param
+
+
+def _check_walk(engine, blob_walk, min_blobs=1):
+    wave, group = engine.decode_v1_walks()
+    assert wave + group >= min_blobs
+    if blob_walk == "group":
+        assert wave == 0
+    return wave, group
+
+
 def _shape_scene():
     """Heat maps whose blobs are NOT one run per row: rings (hole contours are
     keypoints too, utils.py:17), a ring with an island in its hole (RETR_TREE
@@ -103,11 +125,14 @@ def _shape_scene():
 
 
 @pytest.mark.parametrize("W,H", [(656, 368), (480, 480), (1280, 720)])
-def test_literal_contours_shapes(engine, W, H):
+def test_literal_contours_shapes(engine, W, H, blob_walk):
     from oracle import decode_v1
     pred = _shape_scene()
     engine.set_net_out(pred)
     got = engine.decode_v1(BODY_PARTS, POSE_PAIRS, MAPIDX, 1, W, H, 0.1)
+    wave, group = _check_walk(engine, blob_walk, 5)
+    if blob_walk == "wave":
+        assert group == 0          # rings, nested rings, U / C / S / X shapes: none of them trips a guard
     ref = _oracle(pred, W, H)
     _check(got[0], ref)
     # the scene really exercises the literal path: the connected-component
@@ -117,11 +142,14 @@ def test_literal_contours_shapes(engine, W, H):
     assert cc[0].shape != ref[0].shape
 
 
-def test_literal_contours_crowd(engine):
+def test_literal_contours_crowd(engine, blob_walk):
     """60 people at 656x368: merged blobs with several runs per row on some parts."""
     preds = np.stack([synth.synth_net_output(4, 60, COCO_18, 46, 82), synth.synth_net_output(5, 45, COCO_18, 46, 82)])
     engine.set_net_out(preds)
     got = engine.decode_v1(BODY_PARTS, POSE_PAIRS, MAPIDX, 2, 656, 368, 0.1, kp_cap=128, person_cap=256)
+    wave, group = _check_walk(engine, blob_walk, 5)
+    if blob_walk == "wave":
+        assert group == 0
     for b in range(2):
         _check(got[b], _oracle(preds[b:b + 1], 656, 368))
 
@@ -143,13 +171,15 @@ def _noise_scene(seed, parts, level, hs=46, ws=82):
     (7, 0.05, 656, 368, 46, 82), (8, 0.0, 656, 368, 46, 82), (9, 0.12, 656, 368, 46, 82), (10, 0.25, 480, 480, 46, 82),
     (11, 0.1, 1280, 720, 23, 41), (12, 0.3, 333, 247, 46, 82), (13, 0.08, 1920, 1080, 16, 28),
 ])
-def test_literal_contours_noise(engine, seed, level, W, H, hs, ws):
+def test_literal_contours_noise(engine, seed, level, W, H, hs, ws, blob_walk):
     """Arbitrary mask topology (tens of contours per part, contours of up to a
     few thousand vertices): list order, hole borders, nesting and fill all have
     to agree with the literal walk, keypoint by keypoint."""
     pred = _noise_scene(seed, 6, level, hs, ws)   # (coarser maps at the large sizes: the 8192-run capacity)
     engine.set_net_out(pred)
     got = engine.decode_v1(BODY_PARTS, POSE_PAIRS, MAPIDX, 1, W, H, 0.1)
+    _check_walk(engine, blob_walk, 6)   # (blobs with more than 32 border loops or 5 000 pieces -- a mask that is mostly
+                                        #  foreground -- go through the one-group walk in both settings)
     ref = _oracle(pred, W, H)
     _check(got[0], ref)
     assert ref[0].shape[0] > 30
