@@ -669,8 +669,8 @@ __device__ __forceinline__ unsigned v1_gballot(bool p, int lane) {
 // vertices and records, for every border pixel whose right neighbour the search examined and found empty, the
 // contour id on that pixel's piece (the "-nbd" mark of the library: only run ends can carry it).  Returns the
 // vertex count, -1 if the pool is exhausted or the walk does not close.  One group; `verts` is lane 0's.
-__device__ int v1_trace(const V1Grid& g, int x0, int y0, bool is_hole, unsigned short cid, V1Verts& verts,
-                        unsigned short* mark, int lane) {
+__device__ __forceinline__ int v1_trace(const V1Grid& g, int x0, int y0, bool is_hole, unsigned short cid, V1Verts& verts,
+                                        unsigned short* mark, int lane) {
   const int r = lane & 7;
   int n = 0, ok = 1;
   int s_end = is_hole ? 0 : 4;
@@ -731,7 +731,7 @@ struct V1Paint {
 };
 
 // pixels [lo, hi] of piece j (row y) are painted
-__device__ void v1_consider(V1Paint& p, int j, int y, int lo, int hi) {
+__device__ __forceinline__ void v1_consider(V1Paint& p, int j, int y, int lo, int hi) {
   if (__float_as_uint(p.bval[j]) < (unsigned)(p.cur >> 32)) return;  // nothing in the piece can win
   const V1Run r = p.R[p.byrow[j]];
   if (r.bx >= lo && r.bx <= hi) {
@@ -748,9 +748,16 @@ __device__ void v1_consider(V1Paint& p, int j, int y, int lo, int hi) {
 }
 
 // columns [x1, x2] of row y are painted: pieces of ANY blob under them count, as in cv2
-__device__ void v1_paint_span(V1Paint& p, int y, int x1, int x2) {
+__device__ __forceinline__ void v1_paint_span(V1Paint& p, int y, int x1, int x2) {
   if (y < 0 || y >= p.g.H) return;
-  for (int j = p.g.rowoff[y]; j < p.g.rowoff[y + 1]; j++) {
+  int lo = p.g.rowoff[y];
+  const int r1 = p.g.rowoff[y + 1];
+  for (int hi = r1; hi - lo > 4;) {   // a crowded row: skip the pieces that end left of x1
+    const int mid = (lo + hi) >> 1;
+    if (p.g.srun[mid].y < x1) lo = mid + 1;
+    else hi = mid;
+  }
+  for (int j = lo; j < r1; j++) {
     const short2 q = p.g.srun[j];
     if (q.x > x2) break;
     if (q.y < x1) continue;
@@ -772,8 +779,10 @@ __device__ __forceinline__ unsigned long long v1_gmax(unsigned long long k) {
 // GW lanes (8: the one-group walk; 64: the wave of v1_fast_blob): every lane runs the walkers (a few additions per
 // row), lane k paints the k-th row of each GW; outline edges are dealt round-robin.  On return p.cur is the group's
 // maximum in every lane.
+// (forced inline, like the other helpers that take the paint state: one real call is enough to put that state -- the
+// running maximum included -- into scratch memory for the whole kernel)
 template <int GW, bool FILL = true>
-__device__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
+__device__ __forceinline__ void v1_fill_paint(V1Paint& p, const short2* v, int n, int lane) {
   const int W = p.g.W, H = p.g.H, r = lane & (GW - 1), r8 = lane & 7;
   const long long XY_ONE = 1 << 16;
   int xmin = 0x7fffffff, xmax = -0x7fffffff, ymax = -0x7fffffff, ykey = 0x7fffffff;   // ykey = (y << 16) | index
@@ -980,46 +989,71 @@ __device__ __forceinline__ T v1_gl(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// columns x-1, x, x+1 of row y: which are mask pixels (bits 0..2) and in which pieces.  `rel` = the caller's guess:
-// position inside the row of the first piece that starts right of x + 1 (checked with the three reads it costs)
-__device__ __forceinline__ int v1_row3(const V1Grid& g, int x, int y, int& rel, int& p0, int& p1, int& p2) {
-  p0 = p1 = p2 = -1;
-  if (y < 0 || y >= g.H) return 0;
-  const int r0 = g.rowoff[y], r1 = g.rowoff[y + 1];
-  if (r0 == r1) return 0;
+// The 8 neighbours of (x, y) as a bit per direction (E NE N NW W SW S SE) and the piece of each, from the rows
+// y - 1, y, y + 1 -- all three looked up at once: the rows' offsets, then the three pieces around each row's guess
+// (rel[r] = position inside the row of the first piece that starts right of x + 1, the caller's last answer), so a
+// neighbourhood costs two LDS round trips when the guesses hold; a wrong guess is repaired by a binary search.  Only
+// the last two pieces that start at or before x + 1 can reach columns x - 1 .. x + 1 (touching pieces exist at tile
+// seams only, 256 columns apart).  top_xe: the end of the last piece of row y - 1 that starts at or before x + 1;
+// bot_xs: the start of the first piece of row y + 1 that ends at or after x - 1 (for the straight stretches).
+__device__ __forceinline__ int v1_nbhd(const V1Grid& g, int x, int y, int* rel, int* pc, int& top_xe, int& bot_xs) {
   const short2 lo_ = make_short2(-32768, -32768), hi_ = make_short2(32767, 32767);
-  int q = r0 + rel;
-  q = q < r0 ? r0 : (q > r1 ? r1 : q);
-  short2 a = q > r0 ? g.srun[q - 1] : lo_, c = q - 1 > r0 ? g.srun[q - 2] : lo_;
-  const short2 b = q < r1 ? g.srun[q] : hi_;
-  if (!(a.x <= x + 1 && x + 1 < b.x)) {
-    int lo = r0, hi = r1;
-    while (lo < hi) {   // first piece with xs > x + 1
-      const int mid = (lo + hi) >> 1;
-      if (g.srun[mid].x <= x + 1) lo = mid + 1;
-      else hi = mid;
-    }
-    q = lo;
-    a = q > r0 ? g.srun[q - 1] : lo_;
-    c = q - 1 > r0 ? g.srun[q - 2] : lo_;
+  int r0[3], r1[3], q[3];
+  short2 a[3], b[3], c[3];
+  bool in[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int yy = y - 1 + r;
+    in[r] = yy >= 0 && yy < g.H;
+    r0[r] = in[r] ? g.rowoff[yy] : 0;
+    r1[r] = in[r] ? g.rowoff[yy + 1] : 0;
   }
-  rel = q - r0;
-  int bits = 0;
-  // only the last two pieces that start at or before x + 1 can reach these columns (touching pieces exist at tile
-  // seams only, 256 columns apart)
-  if (a.x <= x - 1 && x - 1 <= a.y) { bits |= 1; p0 = q - 1; } else if (c.x <= x - 1 && x - 1 <= c.y) { bits |= 1; p0 = q - 2; }
-  if (a.x <= x && x <= a.y) { bits |= 2; p1 = q - 1; } else if (c.x <= x && x <= c.y) { bits |= 2; p1 = q - 2; }
-  if (a.x <= x + 1 && x + 1 <= a.y) { bits |= 4; p2 = q - 1; } else if (c.x <= x + 1 && x + 1 <= c.y) { bits |= 4; p2 = q - 2; }
-  return bits;
-}
-
-// the 8 neighbours of (x, y) as a bit per direction (E NE N NW W SW S SE) and the piece of each
-__device__ __forceinline__ int v1_nbhd(const V1Grid& g, int x, int y, int* rel, int* pc) {
-  int t0, t1, t2, m0, m1, m2, b0, b1, b2;
-  const int top = v1_row3(g, x, y - 1, rel[0], t0, t1, t2);
-  const int mid = v1_row3(g, x, y, rel[1], m0, m1, m2);
-  const int bot = v1_row3(g, x, y + 1, rel[2], b0, b1, b2);
-  pc[0] = m2; pc[1] = t2; pc[2] = t1; pc[3] = t0; pc[4] = m0; pc[5] = b0; pc[6] = b1; pc[7] = b2;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    int t = r0[r] + rel[r];
+    t = t < r0[r] ? r0[r] : (t > r1[r] ? r1[r] : t);
+    q[r] = t;
+    a[r] = t > r0[r] ? g.srun[t - 1] : lo_;
+    c[r] = t - 1 > r0[r] ? g.srun[t - 2] : lo_;
+    b[r] = t < r1[r] ? g.srun[t] : hi_;
+  }
+  int bits[3];
+  int p[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    if (!(a[r].x <= x + 1 && x + 1 < b[r].x)) {   // the guess was wrong
+      int lo = r0[r], hi = r1[r];
+      while (lo < hi) {   // first piece with xs > x + 1
+        const int mid = (lo + hi) >> 1;
+        if (g.srun[mid].x <= x + 1) lo = mid + 1;
+        else hi = mid;
+      }
+      q[r] = lo;
+      a[r] = lo > r0[r] ? g.srun[lo - 1] : lo_;
+      c[r] = lo - 1 > r0[r] ? g.srun[lo - 2] : lo_;
+      b[r] = lo < r1[r] ? g.srun[lo] : hi_;
+    }
+    rel[r] = q[r] - r0[r];
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int cx = x - 1 + k;
+      p[r][k] = -1;
+      if (a[r].x <= cx && cx <= a[r].y) {
+        m |= 1 << k;
+        p[r][k] = q[r] - 1;
+      } else if (c[r].x <= cx && cx <= c[r].y) {
+        m |= 1 << k;
+        p[r][k] = q[r] - 2;
+      }
+    }
+    bits[r] = m;
+  }
+  top_xe = a[0].y;
+  bot_xs = c[2].y >= x - 1 ? c[2].x : (a[2].y >= x - 1 ? a[2].x : b[2].x);
+  pc[0] = p[1][2]; pc[1] = p[0][2]; pc[2] = p[0][1]; pc[3] = p[0][0]; pc[4] = p[1][0];
+  pc[5] = p[2][0]; pc[6] = p[2][1]; pc[7] = p[2][2];
+  const int top = bits[0], mid = bits[1], bot = bits[2];
   return ((mid >> 2) & 1) | ((top >> 2) & 1) << 1 | ((top >> 1) & 1) << 2 | (top & 1) << 3 | (mid & 1) << 4 |
          (bot & 1) << 5 | ((bot >> 1) & 1) << 6 | ((bot >> 2) & 1) << 7;
 }
@@ -1032,7 +1066,7 @@ __device__ __forceinline__ int v1_nbhd(const V1Grid& g, int x, int y, int* rel, 
 // walkers together ends the fill at the first row where the visits so far exceed n; visits only grow, so a row is
 // painted iff the two edges that cover it were reached within n visits.  `tab`: 6 ints per row (global scratch).
 // Returns false (nothing painted) when the scratch does not fit.
-__device__ bool v1_fill_wave(V1Paint& p, const short2* v, int n, int lane, const V1FastCtx& cx) {
+__device__ __forceinline__ bool v1_fill_wave(V1Paint& p, const short2* v, int n, int lane, const V1FastCtx& cx) {
   const int W = p.g.W, H = p.g.H;
   int xmin = 0x7fffffff, xmax = -0x7fffffff, ymax = -0x7fffffff, ykey = 0x7fffffff;   // ykey = (y << 16) | index
   for (int i = lane; i < n; i += 64) {
@@ -1100,15 +1134,23 @@ __device__ bool v1_fill_wave(V1Paint& p, const short2* v, int n, int lane, const
     }
   }
   v1_wave_sync();
-  for (int y = ymin + lane; y < ymax; y += 64) {
-    const int* e = tab + (y - ymin) * 6;
-    const int a0 = v1_gl(e), a1 = v1_gl(e + 1), a2 = v1_gl(e + 2), b0 = v1_gl(e + 3), b1 = v1_gl(e + 4), b2 = v1_gl(e + 5);
-    if (a2 == 0x7fffffff || b2 == 0x7fffffff || a2 + b2 > n) continue;
-    const long long ex0 = ((long long)(a0 & 0xffff) << 16) + (long long)(y - (a0 >> 16)) * a1;
-    const long long ex1 = ((long long)(b0 & 0xffff) << 16) + (long long)(y - (b0 >> 16)) * b1;
-    const long long xl = ex0 > ex1 ? ex1 : ex0, xr = ex0 > ex1 ? ex0 : ex1;
-    const int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
-    if (xx2 >= 0 && xx1 < W) v1_paint_span(p, y, xx1 < 0 ? 0 : xx1, xx2 >= W ? W - 1 : xx2);
+  // lane k takes rows k * per, k * per + 1, ...: the first round already samples the whole height of the polygon, and
+  // with the wave's maximum after every round the later ones skip most pieces without looking at them
+  const int per = (rows + 63) / 64;
+  for (int k = 0; k < per; k++) {
+    const int y = ymin + lane * per + k;
+    if (y < ymax) {
+      const int* e = tab + (y - ymin) * 6;
+      const int a0 = v1_gl(e), a1 = v1_gl(e + 1), a2 = v1_gl(e + 2), b0 = v1_gl(e + 3), b1 = v1_gl(e + 4), b2 = v1_gl(e + 5);
+      if (a2 != 0x7fffffff && b2 != 0x7fffffff && a2 + b2 <= n) {
+        const long long ex0 = ((long long)(a0 & 0xffff) << 16) + (long long)(y - (a0 >> 16)) * a1;
+        const long long ex1 = ((long long)(b0 & 0xffff) << 16) + (long long)(y - (b0 >> 16)) * b1;
+        const long long xl = ex0 > ex1 ? ex1 : ex0, xr = ex0 > ex1 ? ex0 : ex1;
+        const int xx1 = (int)((xl + 32768) >> 16), xx2 = (int)((xr + 32768) >> 16);
+        if (xx2 >= 0 && xx1 < W) v1_paint_span(p, y, xx1 < 0 ? 0 : xx1, xx2 >= W ? W - 1 : xx2);
+      }
+    }
+    p.cur = v1_gmax<64>(p.cur);
   }
   p.cur = v1_gmax<64>(p.cur);
   return true;
@@ -1117,8 +1159,8 @@ __device__ bool v1_fill_wave(V1Paint& p, const short2* v, int n, int lane, const
 // One wave (all 64 lanes, uniform arguments).  `i` = the blob's number = its outer border's contour, `me` = its root
 // piece, rows y_first .. y_last.  True: every border loop of the blob is in the contour tables, filled, with its
 // arg-max key; false: nothing was changed.
-__device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, int i, int me, int y_first, int y_last,
-                             int lane) {
+__device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, int i, int me,
+                                             int y_first, int y_last, int lane) {
   const int* rowoff = g.rowoff;
   const short2* srun = g.srun;
   [[maybe_unused]] const long long t0_ = V1B_NOW();
@@ -1135,12 +1177,13 @@ __device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, 
   if (lane == 0) V1B_ADD(23, np);
   const int nn = 2 * np;
   int* ltab = cx.ltab;
-  // (2) tables: the pointer-jumping words in LDS when the block has 16 B per piece left, everything else (and those
-  // words otherwise) in the vertex pool
+  // (2) tables (32 B per piece) in LDS when the block has that much left, else in the vertex pool -- generic
+  // pointers, and every read of what another lane wrote goes through v1_gl; the segments' scratch vertices
+  // (2 V1F_K entries per piece) always in the pool
   int a = 0, tb = 0;
   if (lane == 0) {
-    a = v1_bump(cx.s_free, 8 * nn, cx.lds_limit);
-    tb = v1_bump(cx.s_vused, (a < 0 ? V1F_UNITS : V1F_UNITS - 4) * np, cx.fast_cap);
+    a = v1_bump(cx.s_free, 32 * np, cx.lds_limit);
+    tb = v1_bump(cx.s_vused, (a < 0 ? V1F_UNITS : V1F_UNITS - 8) * np, cx.fast_cap);
   }
   a = __shfl(a, 0);
   tb = __shfl(tb, 0);
@@ -1148,23 +1191,18 @@ __device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, 
     if (lane == 0) V1B_ADD(17, 1);
     return false;
   }
-  unsigned short* succ = (unsigned short*)(cx.vpool + tb);          // nn: the next node of the border loop
+  short2* tmp = cx.vpool + tb;                                      // nn x V1F_K: a segment's vertices
+  // (8-byte aligned in the pool: the scratch vertices take 2 K entries per piece, the rounding at most 1)
+  char* tbl = a >= 0 ? cx.lds + a : (char*)(cx.vpool + ((tb + 2 * V1F_K * np + 1) & ~1));
+  unsigned long long* jw = (unsigned long long*)tbl;                // nn: pointer-jumping words
+  unsigned short* succ = (unsigned short*)(jw + nn);                // nn: the next node of the border loop
   unsigned short* st = succ + nn;                                   // nn: predecessor, then first node of the loop
   unsigned short* plist = st + nn;                                  // np: sorted position of the piece
   unsigned short* prow = plist + np;                                // np: its row
   unsigned char* cntfl = (unsigned char*)(prow + np);               // nn: vertices | 0x40 sweeps east | 0x80 node
   unsigned char* loop = cntfl + nn;                                 // nn: (first nodes only) number of the loop
-  short2* tmp = (short2*)(loop + nn);                               // nn x V1F_K: a segment's vertices
-  // nn words, 8-byte aligned (the tables above take 4 + 2 K entries per piece, these 4, the rounding at most 1)
-  unsigned long long* jwg = (unsigned long long*)(cx.vpool + ((tb + (4 + 2 * V1F_K) * np + 1) & ~1));
-  const bool jl = a >= 0;
-  auto jw_ld = [&](int k) -> unsigned long long {
-    return jl ? ((const unsigned long long*)(cx.lds + a))[k] : v1_gl(jwg + k);
-  };
-  auto jw_st = [&](int k, unsigned long long w) {
-    if (jl) ((unsigned long long*)(cx.lds + a))[k] = w;
-    else jwg[k] = w;
-  };
+  auto jw_ld = [&](int k) -> unsigned long long { return v1_gl(jw + k); };
+  auto jw_st = [&](int k, unsigned long long w) { jw[k] = w; };
   {
     int base = 0;
     for (int yb = y_first; yb <= y_last; yb += 64) {
@@ -1189,6 +1227,9 @@ __device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, 
   [[maybe_unused]] const long long t1_ = V1B_NOW();
   // (3) a lane per node: its segment
   int bad = 0;
+#ifdef V1B_STAMP
+  int dbg_steps = 0;
+#endif
   for (int m = lane; m < nn; m += 64) {
     const int j = v1_gl(plist + (m >> 1)), side = m & 1, y = v1_gl(prow + (m >> 1));
     const short2 q = srun[j];
@@ -1197,8 +1238,9 @@ __device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, 
                                    : (j + 1 < rowoff[y + 1] && srun[j + 1].x == q.y + 1));   // not cut at a tile seam
     if (crack) {
       int px = side ? q.y : q.x, py = y;
-      int rel[3] = {0, 0, 0}, pc[8];
-      int nb = v1_nbhd(g, px, py, rel, pc);
+      const int rg = j - rowoff[y] + 1;   // (pieces of adjacent rows of a blob line up: a first guess for all three rows)
+      int rel[3] = {rg, rg, rg}, pc[8], top_xe, bot_xs;
+      int nb = v1_nbhd(g, px, py, rel, pc, top_xe, bot_xs);
       const int d0 = side ? 0 : 4;
       // clockwise from the crack: the pixel the walk comes from; a crack whose search passes the pixel's other side
       // (empty too) is swept by the step that starts there
@@ -1210,8 +1252,33 @@ __device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, 
         int back = (d0 - tcw) & 7, cnt = 0, j3 = j;
         cf = 0x80;
         nxt = -1;
+        bool straight = false;   // the last move repeated the one before it
         for (int step = 0; step < V1F_STEPS; step++) {
-          if (step) nb = v1_nbhd(g, px, py, rel, pc);
+#ifdef V1B_STAMP
+          dbg_steps++;
+#endif
+          if (step) {
+            // (ONE neighbourhood per pass of this loop, whatever a lane does with it: the lanes of a wave go through
+            // every path any of them takes)
+            nb = v1_nbhd(g, px, py, rel, pc, top_xe, bot_xs);
+            // A straight stretch along the top of a run (westwards: NE, N, NW empty, W set) or along its bottom
+            // (eastwards: SW, S, SE empty, E set): every step up to the run's end, or to the pixel diagonally below /
+            // above the nearest mask pixel of the neighbouring row, is the same -- the same move, nothing emitted,
+            // no side swept -- and is taken at once: the pass ends with the lane at the stretch's last pixel
+            int xt = px;
+            if (straight && back == 0 && (nb & 0x1e) == 0x10) {
+              const int xs3 = g.srun[j3].x;
+              xt = top_xe + 1 > xs3 ? top_xe + 1 : xs3;
+            } else if (straight && back == 4 && (nb & 0xe1) == 0x01) {
+              const int xe3 = g.srun[j3].y;
+              xt = bot_xs - 1 < xe3 ? bot_xs - 1 : xe3;
+            }
+            if (xt != px) {
+              px = xt;
+              straight = false;
+              continue;
+            }
+          }
           const int sh = (back + 1) & 7;
           const int rot = ((nb >> sh) | (nb << (8 - sh))) & 0xff;
           const int z = __ffs(rot) - 1;              // empty neighbours swept before the first set one
@@ -1232,43 +1299,13 @@ __device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, 
           }
           px += v1_dx(sp);
           py += v1_dy(sp);
-          j3 = pc[sp];
+          // (selects, not pc[sp]: an array indexed at run time lives in scratch memory)
+          j3 = sp == 0 ? pc[0] : sp == 1 ? pc[1] : sp == 2 ? pc[2] : sp == 3 ? pc[3] : sp == 4 ? pc[4] : sp == 5 ? pc[5]
+                                                                                                  : sp == 6 ? pc[6] : pc[7];
           back = sp ^ 4;
+          straight = !turn;
           const int dyv = v1_dy(sp);
           if (dyv > 0) { rel[0] = rel[1]; rel[1] = rel[2]; } else if (dyv < 0) { rel[2] = rel[1]; rel[1] = rel[0]; }
-          if (!turn && sp == 4) {
-            // second step west in a row: along the top of a run.  Up to the run's first pixel, or to the pixel
-            // below-right of the nearest mask pixel of the row above, every step is the same (west, nothing emitted,
-            // no side swept)
-            int qe = -32768;
-            if (py > 0) {
-              const int r0 = rowoff[py - 1];
-              int lo = r0, hi = rowoff[py];
-              while (lo < hi) {   // first piece with xs > px + 1
-                const int mid = (lo + hi) >> 1;
-                if (srun[mid].x <= px + 1) lo = mid + 1;
-                else hi = mid;
-              }
-              if (lo > r0) qe = srun[lo - 1].y;
-            }
-            const int xs3 = srun[j3].x, xt = qe + 1 > xs3 ? qe + 1 : xs3;
-            if (xt < px) px = xt;
-          } else if (!turn && sp == 0) {
-            // the same eastwards along the bottom of a run
-            int qs = 32767;
-            if (py + 1 < g.H) {
-              const int r1 = rowoff[py + 2];
-              int lo = rowoff[py + 1], hi = r1;
-              while (lo < hi) {   // first piece with xe >= px - 1
-                const int mid = (lo + hi) >> 1;
-                if (srun[mid].y < px - 1) lo = mid + 1;
-                else hi = mid;
-              }
-              if (lo < r1) qs = srun[lo].x;
-            }
-            const int xe3 = srun[j3].y, xt = qs - 1 < xe3 ? qs - 1 : xe3;
-            if (xt > px) px = xt;
-          }
         }
         if (nxt < 0) {
           bad = 1;
@@ -1281,6 +1318,15 @@ __device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, 
     cntfl[m] = (unsigned char)cf;
     st[m] = 0xffff;
     loop[m] = 0xff;
+#ifdef V1B_STAMP
+    {
+      int mx = dbg_steps;
+      for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(mx, o); mx = mx > t ? mx : t; }
+      V1B_ADD(31, dbg_steps);
+      if (lane == 0) V1B_ADD(13, mx);
+      dbg_steps = 0;
+    }
+#endif
   }
   v1_wave_sync();
   [[maybe_unused]] const long long t2_ = V1B_NOW();
@@ -1466,7 +1512,7 @@ __device__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const V1FastCtx& cx, 
 // scene has 5-6 blobs that need the literal walk, and walks that share a wave run one after the other)
 // ---------------------------------------------------------------------------
 #define V1B_THREADS 512
-__device__ __forceinline__ int uf_find(const int* parent, int i) {
+__device__ __forceinline__ int uf_root(const int* parent, int i) {
   // (relaxed atomic loads, not volatile ones: other threads hook roots meanwhile, and a volatile access keeps the
   // pointer generic -- flat loads -- where the table is known to be in LDS)
   int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1478,8 +1524,8 @@ __device__ __forceinline__ int uf_find(const int* parent, int i) {
 }
 __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   while (true) {
-    a = uf_find(parent, a);
-    b = uf_find(parent, b);
+    a = uf_root(parent, a);
+    b = uf_root(parent, b);
     if (a == b) return;
     if (a < b) {
       const int t = a;
@@ -1589,8 +1635,10 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
     byrow[pos] = (unsigned short)i;
     srun[pos] = make_short2((short)r.xs, (short)r.xe);
     bval[pos] = r.best;
+    mark[pos] = (unsigned short)r.y;   // (the row, for the component search; the sort below moves pieces inside a row only)
   }
   __syncthreads();
+  if (tid == 0) V1B_ADD(27, V1B_NOW() - tb0_);
   for (int y = tid; y < H; y += V1B_THREADS) {   // order each row by xs (a handful of pieces: insertion sort)
     const int lo = rowoff[y], hi = rowoff[y + 1];
     for (int a = lo + 1; a < hi; a++) {
@@ -1610,24 +1658,72 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
     }
   }
   __syncthreads();
-  // union pieces that touch: same row across a tile seam (xs == left neighbour's xe + 1); previous row: 8-connectivity
+  if (tid == 0) V1B_ADD(28, V1B_NOW() - tb0_);
+  // Connected components of the pieces (8-connectivity: a piece touches the pieces of the previous row that reach
+  // into [xs - 1, xe + 1], and its left neighbour across a tile seam).  Pieces are numbered in raster order, so every
+  // piece first hangs under the first piece it touches above or to its left; pointer jumping then makes every piece
+  // point at its tree's root (a blob's height halves per round); a union-find pass over the touching pairs then
+  // merges the trees that meet further down (a bump is one tree from the start; a U or an M is not), and a second
+  // jumping pass flattens what that built.  A union-find from single pieces, with finds from every piece, took 300 k
+  // cycles here on a crowded 1080p plane: it climbs a piece per row.
+  auto above = [&](int y, const short2 r, int& k1) {   // first piece of row y - 1 that ends at or after xs - 1
+    int k = rowoff[y - 1];
+    k1 = rowoff[y];
+    for (int hi = k1; hi - k > 4;) {
+      const int mid = (k + hi) >> 1;
+      if (srun[mid].y < r.x - 1) k = mid + 1;
+      else hi = mid;
+    }
+    while (k < k1 && srun[k].y < r.x - 1) k++;
+    return k;
+  };
   for (int j = tid; j < n; j += V1B_THREADS) {
-    const int y = R[byrow[j]].y;
+    const int y = mark[j];   // (the row, left there by the scatter; the marks are cleared below)
+    const short2 r = srun[j];
+    int link = j;
+    if (j > rowoff[y] && srun[j - 1].y + 1 == r.x) link = j - 1;
+    if (y > 0) {
+      int k1;
+      const int k = above(y, r, k1);
+      if (k < k1 && srun[k].x <= r.y + 1) link = k;
+    }
+    parent[j] = link;
+  }
+  __syncthreads();
+  auto jump = [&]() {   // pointer jumping to the roots, four pieces of a thread at a time
+    for (;;) {
+      int ch = 0;
+      for (int j0 = tid; j0 < n; j0 += 4 * V1B_THREADS) {
+        int p[4], gp[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = j0 + u * V1B_THREADS < n ? parent[j0 + u * V1B_THREADS] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) gp[u] = parent[p[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (j0 + u * V1B_THREADS < n && gp[u] != p[u]) {
+            parent[j0 + u * V1B_THREADS] = gp[u];
+            ch = 1;
+          }
+      }
+      if (!__syncthreads_or(ch)) break;
+    }
+  };
+  jump();
+  // the trees are flat now: a union per touching pair is two short finds and, when the trees differ, one hook
+  for (int j = tid; j < n; j += V1B_THREADS) {
+    const int y = mark[j];
     const short2 r = srun[j];
     if (j > rowoff[y] && srun[j - 1].y + 1 == r.x) uf_union(parent, j, j - 1);
-    if (y > 0)
-      for (int k = rowoff[y - 1]; k < rowoff[y]; k++) {
-        const short2 q = srun[k];
-        if (q.x > r.y + 1) break;
-        if (q.y >= r.x - 1) uf_union(parent, j, k);
-      }
+    if (y > 0) {
+      int k1;
+      for (int k = above(y, r, k1); k < k1 && srun[k].x <= r.y + 1; k++) uf_union(parent, j, k);
+    }
   }
   __syncthreads();
-  for (int j = tid; j < n; j += V1B_THREADS) {   // full path compression: parent[j] = the blob's root from here on
-    const int root = uf_find(parent, j);
-    parent[j] = root;                    // (concurrent finds read either an ancestor or the root: both lead there)
-  }
-  __syncthreads();
+  jump();
+  for (int j = tid; j < n; j += V1B_THREADS) mark[j] = 0;
+  if (tid == 0) V1B_ADD(29, V1B_NOW() - tb0_);
   // the blobs = the roots, in any order; a root's piece carries its blob's number (complemented) for a moment so
   // that every piece finds it in one step
   for (int j = tid; j < n; j += V1B_THREADS)
@@ -1636,6 +1732,7 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
       if (s < kp_cap) roots[s] = j; else *overflow = 1;
     }
   __syncthreads();
+  if (tid == 0) V1B_ADD(30, V1B_NOW() - tb0_);
   const int nr = s_nroot < kp_cap ? s_nroot : kp_cap;
   for (int i = tid; i < nr; i += V1B_THREADS) {
     b_best[i] = 0ull;

@@ -44,3 +44,6 @@ print(f"fast path: {cyc[16]} blobs done, {cyc[17]} without table space, {cyc[18]
       f"{cyc[23] / max(1, cyc[16] + cyc[17] + cyc[18]):.0f}, loops {cyc[25] / nf:.2f}, vertices {cyc[26] / nf:.0f}; cycles: piece list "
       f"{cyc[19] / nf:.0f}, segments {cyc[20] / nf:.0f}, loop walk {cyc[21] / nf:.0f}, placement {cyc[22] / nf:.0f}, "
       f"fills {cyc[24] / nf:.0f}; whole call (all blobs) {cyc[2] / max(1, cyc[5]):.0f}")
+print(f"setup, cycles per block from the kernel's start: pieces scattered {cyc[27] / nb:.0f}, rows sorted {cyc[28] / nb:.0f}, "
+      f"unions {cyc[29] / nb:.0f}, roots {cyc[30] / nb:.0f}, walks start {cyc[7] / nb:.0f}")
+print(f"segments: {cyc[31] / max(1, cyc[16]):.0f} steps per blob over all lanes, {cyc[13] / max(1, cyc[16]):.0f} = the sum over a blob's rounds of the longest segment")
