@@ -261,7 +261,9 @@ int ph_decode_v2_times(ph_ctx* ctx, float* ms3);
  *   n_persons int32 [B]
  *   persons   f64   [B][person_cap][n_parts+1]   keypoint ids (-1 = missing) + total score
  * Returns -2 when a capacity (kp_cap contours per part, person_cap people, 8192
- * mask runs or 65536 pooled contour vertices per part) is exceeded. */
+ * mask runs per part, or the part's pool of contour vertices: 65536 for the
+ * one-group walk, as before, beside 196608 entries for the wave walk's tables)
+ * is exceeded. */
 int ph_decode_v1(ph_ctx* ctx, const ph_v1_model* model, int B, int W0, int H0, float conf_thres, int kp_cap,
                  int person_cap, int32_t* n_kps, float* kps, int32_t* n_pairs, double* pairs, int32_t* n_persons,
                  double* persons);

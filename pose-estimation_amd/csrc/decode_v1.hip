@@ -8,12 +8,13 @@
 //   K-A  per 16x256 tile: bilinear resize -> 3x3 Gaussian -> threshold -> row
 //        runs of the mask with their first-raster maxima (tiles whose source
 //        cells are all below threshold are skipped);
-//   K-B  per (frame, part): runs sorted by (row, column) in LDS, lock-free
-//        union-find over touching runs (8-connectivity) = the blobs
+//   K-B  per (frame, part): runs sorted by (row, column) in LDS, connected
+//        components of touching runs (8-connectivity) = the blobs
 //        cv2.findContours traces; a blob with one run per row gives its
 //        arg-max, every other blob is walked literally (border following,
-//        hole borders, fillConvexPoly) by a group of 8 lanes; RETR_TREE
-//        list order;
+//        hole borders, fillConvexPoly): by a wave that finds all its border
+//        loops at once (v1_fast_blob), else by a group of 8 lanes that
+//        follows one border pixel after the other; RETR_TREE list order;
 //   K-C  per (frame, limb): 10-sample nearest-pixel PAF line integral in fp64,
 //        per-A arg-max, ordered compaction;
 //   K-D  per frame: person assembly in LDS.
@@ -1561,7 +1562,7 @@ __global__ __launch_bounds__(V1B_THREADS) void v1_blobs_kernel(const float* __re
   // laid out for the n pieces this plane has, not for run_cap: what is left of the block's LDS (sized for run_cap by
   // the launcher) is the fast walk's table space
   const int nn = (n + 3) & ~3;
-  int* parent = ismem;                                          // n: union-find, then each piece's blob root
+  int* parent = ismem;                                          // n: component links, then each piece's blob root
   int* rowoff = parent + nn;                                    // H + 2
   int* roots = rowoff + H + 2;                                  // kp_cap: the blobs' root pieces
   float* bval = (float*)(roots + kp_cap);                       // n: the piece's maximum

@@ -84,14 +84,22 @@ def v1_case(eng, seed):
         pred[0, :parts] = smooth_noise(rng, parts, hs, ws, int(rng.integers(1, 4))) * 0.2 + float(rng.uniform(-0.1, 0.3))
         pred[0, 19:] = smooth_noise(rng, 38, hs, ws, 3) * 0.3
         what = f"noise parts={parts}"
-    recipe = f"V1 seed={seed} net {hs}x{ws} image {W}x{H} {what}"
+    group = seed % 4 == 3     # every fourth case through the one-group walk of the irregular blobs only
+    recipe = f"V1 seed={seed} net {hs}x{ws} image {W}x{H} {what}" + (" (one-group walk)" if group else "")
     eng.set_net_out(pred)
     try:
+        if group:
+            os.environ["POSEHIP_V1_FAST"] = "0"
         got = eng.decode_v1(BP, PP, MAPIDX, 1, W, H, 0.1, kp_cap=256, person_cap=1024)
     except Exception as e:   # capacity (-2) is a legal answer on the densest noise maps
         if "capacity" in str(e):
             return recipe + " -> capacity exceeded (skipped)"
         raise
+    finally:
+        os.environ.pop("POSEHIP_V1_FAST", None)
+    wave_n, group_n = eng.decode_v1_walks()
+    assert not (group and wave_n), recipe
+    recipe += f" [{wave_n} blobs by a wave, {group_n} by one group]"
     klist, people_g, ex = got[0]
     rk, rp, ri = decode_v1.postprocess_multi(pred, BP, PP, MAPIDX, W, H, 0.1, return_intermediates=True)
     assert klist.shape == rk.shape and np.array_equal(klist, rk), recipe + ": keypoints"
