@@ -559,13 +559,13 @@ struct V1Grid {
 
 #ifdef V1B_STAMP
 // Diagnostic build only (tools/v1_blobs_stamp.py): where v1_blobs_kernel spends its time.
-__device__ unsigned long long v1b_dbg[32];
+__device__ unsigned long long v1b_dbg[40];
 extern "C" int ph_debug_v1_blobs(unsigned long long* out, int reset) {
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[40] = {0};
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(v1b_dbg), z, sizeof(z));
   }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(v1b_dbg), 32 * sizeof(unsigned long long));
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(v1b_dbg), 40 * sizeof(unsigned long long));
 }
 #define V1B_ADD(i, v) atomicAdd(&v1b_dbg[i], (unsigned long long)(v))
 #define V1B_NOW() __builtin_readcyclecounter()
@@ -613,7 +613,9 @@ __device__ __forceinline__ int v1_piece_near(const V1Grid& g, int x, int y, int&
 }
 
 // the smoothed map at one pixel, with the operations of v1_runs_kernel (resize, row pass, column pass)
-__device__ float v1_smooth_at(const float* src, int hs, int ws, int W, int H, int x, int y) {
+// (not inlined: the pixel-by-pixel re-evaluation is rare -- under-filled shapes only -- and its 36 loads at every place
+// a span is painted made the blobs kernel outgrow the instruction cache)
+__device__ __attribute__((noinline)) float v1_smooth_at(const float* src, int hs, int ws, int W, int H, int x, int y) {
   float t[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -1157,6 +1159,19 @@ __device__ __forceinline__ bool v1_fill_wave(V1Paint& p, const short2* v, int n,
   return true;
 }
 
+// a table of the wave walk: in LDS or, when the block had none left, in the vertex pool
+template <typename T>
+struct V1Tab {
+  T* l;
+  T* g;
+  bool in_lds;
+  __device__ __forceinline__ T get(int k) const { return in_lds ? l[k] : v1_gl(g + k); }
+  __device__ __forceinline__ void set(int k, T v) const {
+    if (in_lds) l[k] = v;
+    else g[k] = v;
+  }
+};
+
 // One wave (all 64 lanes, uniform arguments).  `i` = the blob's number = its outer border's contour, `me` = its root
 // piece, rows y_first .. y_last.  True: every border loop of the blob is in the contour tables, filled, with its
 // arg-max key; false: nothing was changed.
@@ -1166,13 +1181,24 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
   const short2* srun = g.srun;
   [[maybe_unused]] const long long t0_ = V1B_NOW();
   // (1) the blob's pieces, a lane per row
-  int np = 0;
+  int np = 0, xmin = 0x7fff, xmax = -1;
   for (int yb = y_first; yb <= y_last; yb += 64) {
     const int y = yb + lane;
     int c = 0;
     if (y <= y_last)
-      for (int j = rowoff[y]; j < rowoff[y + 1]; j++) c += cx.parent[j] == me;
+      for (int j = rowoff[y]; j < rowoff[y + 1]; j++)
+        if (cx.parent[j] == me) {
+          const short2 q = srun[j];
+          xmin = q.x < xmin ? q.x : xmin;
+          xmax = q.y > xmax ? q.y : xmax;
+          c++;
+        }
     np += __shfl(v1_wave_incl_scan(c, lane), 63);
+  }
+  for (int o = 32; o; o >>= 1) {
+    const int t0 = __shfl_xor(xmin, o), t1 = __shfl_xor(xmax, o);
+    xmin = t0 < xmin ? t0 : xmin;
+    xmax = t1 > xmax ? t1 : xmax;
   }
   if (np < 1 || np > 5000) return false;   // (16-bit vertex sums: at most V1F_K per node)
   if (lane == 0) V1B_ADD(23, np);
@@ -1181,12 +1207,19 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
   // (2) tables (32 B per piece) in LDS when the block has that much left, else in the vertex pool -- generic
   // pointers, and every read of what another lane wrote goes through v1_gl; the segments' scratch vertices
   // (2 V1F_K entries per piece) always in the pool
-  int a = 0, tb = 0;
+  // and, when the block has that left as well, a bitmap of the blob's bounding box (one empty pixel around it) for the
+  // segment walk: a pixel's neighbourhood is then six word reads instead of three searches in the rows' pieces
+  const int bw = (xmax - xmin + 3 + 31) / 32 + 1, bh = y_last - y_first + 3;   // words per row (one to spare), rows
+  int a = 0, tb = 0, ab = -1;
   if (lane == 0) {
     a = v1_bump(cx.s_free, 32 * np, cx.lds_limit);
+    // (only while plenty is left: the tables of the blobs still to come matter more -- from the pool they cost a wave
+    // six times the set-up time per round of segments)
+    if (a >= 0) ab = v1_bump(cx.s_free, bw * bh * 4, cx.lds_limit - 24576);
     tb = v1_bump(cx.s_vused, (a < 0 ? V1F_UNITS : V1F_UNITS - 8) * np, cx.fast_cap);
   }
   a = __shfl(a, 0);
+  ab = __shfl(ab, 0);
   tb = __shfl(tb, 0);
   if (tb < 0) {
     if (lane == 0) V1B_ADD(17, 1);
@@ -1194,16 +1227,31 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
   }
   short2* tmp = cx.vpool + tb;                                      // nn x V1F_K: a segment's vertices
   // (8-byte aligned in the pool: the scratch vertices take 2 K entries per piece, the rounding at most 1)
-  char* tbl = a >= 0 ? cx.lds + a : (char*)(cx.vpool + ((tb + 2 * V1F_K * np + 1) & ~1));
-  unsigned long long* jw = (unsigned long long*)tbl;                // nn: pointer-jumping words
-  unsigned short* succ = (unsigned short*)(jw + nn);                // nn: the next node of the border loop
-  unsigned short* st = succ + nn;                                   // nn: predecessor, then first node of the loop
-  unsigned short* plist = st + nn;                                  // np: sorted position of the piece
-  unsigned short* prow = plist + np;                                // np: its row
-  unsigned char* cntfl = (unsigned char*)(prow + np);               // nn: vertices | 0x40 sweeps east | 0x80 node
-  unsigned char* loop = cntfl + nn;                                 // nn: (first nodes only) number of the loop
-  auto jw_ld = [&](int k) -> unsigned long long { return v1_gl(jw + k); };
-  auto jw_st = [&](int k, unsigned long long w) { jw[k] = w; };
+  // (the tables: LDS pointers and global pointers kept apart -- through ONE generic pointer every access became a flat
+  // instruction, and a flat load waits for the wave's outstanding global stores, the scratch vertices, as well)
+  const bool tl = a >= 0;
+  char* const tl_base = cx.lds + (tl ? a : 0);
+  char* const tg_base = (char*)(cx.vpool + ((tb + 2 * V1F_K * np + 1) & ~1));
+  V1Tab<unsigned long long> jw = {(unsigned long long*)tl_base, (unsigned long long*)tg_base, tl};   // nn: jumping words
+  V1Tab<unsigned short> succ = {(unsigned short*)(tl_base + 8 * nn), (unsigned short*)(tg_base + 8 * nn), tl};     // nn: next node
+  V1Tab<unsigned short> st = {(unsigned short*)(tl_base + 10 * nn), (unsigned short*)(tg_base + 10 * nn), tl};     // nn: predecessor, then the loop's first node
+  V1Tab<unsigned short> plist = {(unsigned short*)(tl_base + 12 * nn), (unsigned short*)(tg_base + 12 * nn), tl};  // np: sorted position of the piece
+  V1Tab<unsigned short> prow = {(unsigned short*)(tl_base + 13 * nn), (unsigned short*)(tg_base + 13 * nn), tl};   // np: its row
+  V1Tab<unsigned char> cntfl = {(unsigned char*)(tl_base + 14 * nn), (unsigned char*)(tg_base + 14 * nn), tl};     // nn: vertices | 0x40 sweeps east | 0x80 node
+  V1Tab<unsigned char> loop = {(unsigned char*)(tl_base + 15 * nn), (unsigned char*)(tg_base + 15 * nn), tl};      // nn: (first nodes) number of the loop
+  auto jw_ld = [&](int k) -> unsigned long long { return jw.get(k); };
+  auto jw_st = [&](int k, unsigned long long w) { jw.set(k, w); };
+  const bool bm = ab >= 0;
+  if (lane == 0) {
+    V1B_ADD(32, bm ? 1 : 0);
+    V1B_ADD(33, a >= 0 ? 1 : 0);
+  }
+  unsigned* bmp = (unsigned*)(cx.lds + (bm ? ab : 0));   // bit (x - xmin + 1) of row (y - y_first + 1)
+  const int bx0 = xmin - 1, by0 = y_first - 1;
+  if (bm) {
+    for (int k = lane; k < bw * bh; k += 64) bmp[k] = 0u;
+    v1_wave_sync();
+  }
   {
     int base = 0;
     for (int yb = y_first; yb <= y_last; yb += 64) {
@@ -1216,10 +1264,19 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
       if (y <= y_last)
         for (int j = rowoff[y]; j < rowoff[y + 1]; j++)
           if (cx.parent[j] == me) {
-            plist[pos] = (unsigned short)j;
-            prow[pos] = (unsigned short)y;
+            plist.set(pos, (unsigned short)j);
+            prow.set(pos, (unsigned short)y);
             cx.mark[j] = (unsigned short)(pos + 1);   // (for the moment: the piece's place in the list)
             pos++;
+            if (bm) {   // (a row is one lane's: plain read-modify-write)
+              const short2 q = srun[j];
+              unsigned* row = bmp + (y - by0) * bw;
+              const int b0 = q.x - bx0, b1 = q.y - bx0;
+              for (int w = b0 >> 5; w <= (b1 >> 5); w++) {
+                const int lo = w == (b0 >> 5) ? (b0 & 31) : 0, hi = w == (b1 >> 5) ? (b1 & 31) : 31;
+                row[w] |= (hi == 31 ? 0xffffffffu : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+              }
+            }
           }
       base += __shfl(incl, 63);
     }
@@ -1232,7 +1289,9 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
   int dbg_steps = 0;
 #endif
   for (int m = lane; m < nn; m += 64) {
-    const int j = v1_gl(plist + (m >> 1)), side = m & 1, y = v1_gl(prow + (m >> 1));
+    [[maybe_unused]] const long long ts0_ = V1B_NOW();
+    [[maybe_unused]] long long ts1_ = ts0_, ts2_ = ts0_;
+    const int j = plist.get((m >> 1)), side = m & 1, y = prow.get((m >> 1));
     const short2 q = srun[j];
     int cf = 0, nxt = 0xffff;
     const bool crack = !(side == 0 ? (j > rowoff[y] && srun[j - 1].y + 1 == q.x)
@@ -1240,8 +1299,41 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
     if (crack) {
       int px = side ? q.y : q.x, py = y;
       const int rg = j - rowoff[y] + 1;   // (pieces of adjacent rows of a blob line up: a first guess for all three rows)
-      int rel[3] = {rg, rg, rg}, pc[8], top_xe, bot_xs;
-      int nb = v1_nbhd(g, px, py, rel, pc, top_xe, bot_xs);
+      int rel[3] = {rg, rg, rg}, pc[8], top_xe = 0, bot_xs = 0;
+      for (int k = 0; k < 8; k++) pc[k] = -1;
+      auto hood = [&]() -> int {
+        if (!bm) return v1_nbhd(g, px, py, rel, pc, top_xe, bot_xs);
+        const int bx = px - bx0;
+        const unsigned* r1 = bmp + (py - by0) * bw;
+        const int w = (bx - 1) >> 5, sft = (bx - 1) & 31;
+        const unsigned long long vt = r1[w - bw] | (unsigned long long)r1[w - bw + 1] << 32;
+        const unsigned long long vm = r1[w] | (unsigned long long)r1[w + 1] << 32;
+        const unsigned long long vb = r1[w + bw] | (unsigned long long)r1[w + bw + 1] << 32;
+        const int top = (int)(vt >> sft) & 7, mid = (int)(vm >> sft) & 7, bot = (int)(vb >> sft) & 7;
+        return ((mid >> 2) & 1) | ((top >> 2) & 1) << 1 | ((top >> 1) & 1) << 2 | (top & 1) << 3 | (mid & 1) << 4 |
+               (bot & 1) << 5 | ((bot >> 1) & 1) << 6 | ((bot >> 2) & 1) << 7;
+      };
+      // bitmap rows: the first bit of the wanted kind at or left of / at or right of position p (the margins are empty,
+      // so an empty bit is always found; -1 / 1 << 30 when no set bit is)
+      auto left_of = [&](const unsigned* row, int p, bool set) -> int {
+        int w = p >> 5;
+        unsigned mk = (set ? row[w] : ~row[w]) & ((p & 31) == 31 ? 0xffffffffu : ((2u << (p & 31)) - 1u));
+        while (!mk) {
+          if (--w < 0) return -1;
+          mk = set ? row[w] : ~row[w];
+        }
+        return (w << 5) + 31 - __clz((int)mk);
+      };
+      auto right_of = [&](const unsigned* row, int p, bool set) -> int {
+        int w = p >> 5;
+        unsigned mk = (set ? row[w] : ~row[w]) & ~((1u << (p & 31)) - 1u);
+        while (!mk) {
+          if (++w >= bw) return 1 << 30;
+          mk = set ? row[w] : ~row[w];
+        }
+        return (w << 5) + __ffs((int)mk) - 1;
+      };
+      int nb = hood();
       const int d0 = side ? 0 : 4;
       // clockwise from the crack: the pixel the walk comes from; a crack whose search passes the pixel's other side
       // (empty too) is swept by the step that starts there
@@ -1254,6 +1346,7 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
         cf = 0x80;
         nxt = -1;
         bool straight = false;   // the last move repeated the one before it
+        ts1_ = V1B_NOW();
         for (int step = 0; step < V1F_STEPS; step++) {
 #ifdef V1B_STAMP
           dbg_steps++;
@@ -1261,18 +1354,30 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
           if (step) {
             // (ONE neighbourhood per pass of this loop, whatever a lane does with it: the lanes of a wave go through
             // every path any of them takes)
-            nb = v1_nbhd(g, px, py, rel, pc, top_xe, bot_xs);
+            nb = hood();
             // A straight stretch along the top of a run (westwards: NE, N, NW empty, W set) or along its bottom
             // (eastwards: SW, S, SE empty, E set): every step up to the run's end, or to the pixel diagonally below /
             // above the nearest mask pixel of the neighbouring row, is the same -- the same move, nothing emitted,
             // no side swept -- and is taken at once: the pass ends with the lane at the stretch's last pixel
             int xt = px;
             if (straight && back == 0 && (nb & 0x1e) == 0x10) {
-              const int xs3 = g.srun[j3].x;
-              xt = top_xe + 1 > xs3 ? top_xe + 1 : xs3;
+              if (bm) {
+                const unsigned* r1 = bmp + (py - by0) * bw;
+                const int bx = px - bx0, za = left_of(r1, bx - 1, false), sa = left_of(r1 - bw, bx + 1, true);
+                xt = (za > sa ? za : sa) + 1 + bx0;
+              } else {
+                const int xs3 = g.srun[j3].x;
+                xt = top_xe + 1 > xs3 ? top_xe + 1 : xs3;
+              }
             } else if (straight && back == 4 && (nb & 0xe1) == 0x01) {
-              const int xe3 = g.srun[j3].y;
-              xt = bot_xs - 1 < xe3 ? bot_xs - 1 : xe3;
+              if (bm) {
+                const unsigned* r1 = bmp + (py - by0) * bw;
+                const int bx = px - bx0, za = right_of(r1, bx + 1, false), sa = right_of(r1 + bw, bx - 1, true);
+                xt = (za < sa ? za : sa) - 1 + bx0;
+              } else {
+                const int xe3 = g.srun[j3].y;
+                xt = bot_xs - 1 < xe3 ? bot_xs - 1 : xe3;
+              }
             }
             if (xt != px) {
               px = xt;
@@ -1288,7 +1393,8 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
           const int dw = (4 - sh) & 7, de = (0 - sh) & 7;
           const bool sw = dw < z, se = de < z;
           if (step > 0 && (sw || se)) {
-            nxt = 2 * ((int)cx.mark[j3] - 1) + ((sw && (!se || dw < de)) ? 0 : 1);
+            if (bm) j3 = v1_piece_at(g, px, py);   // (the bitmap walk does not keep track of the pieces)
+            nxt = j3 < 0 ? -1 : 2 * ((int)cx.mark[j3] - 1) + ((sw && (!se || dw < de)) ? 0 : 1);
             break;
           }
           if (step == 0 && se) cf |= 0x40;
@@ -1308,6 +1414,7 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
           const int dyv = v1_dy(sp);
           if (dyv > 0) { rel[0] = rel[1]; rel[1] = rel[2]; } else if (dyv < 0) { rel[2] = rel[1]; rel[1] = rel[0]; }
         }
+        ts2_ = V1B_NOW();
         if (nxt < 0) {
           bad = 1;
           nxt = 0xffff;
@@ -1315,12 +1422,15 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
         cf |= cnt;
       }
     }
-    succ[m] = (unsigned short)nxt;
-    cntfl[m] = (unsigned char)cf;
-    st[m] = 0xffff;
-    loop[m] = 0xff;
+    succ.set(m, (unsigned short)nxt);
+    cntfl.set(m, (unsigned char)cf);
+    st.set(m, 0xffff);
+    loop.set(m, 0xff);
 #ifdef V1B_STAMP
     {
+      long long d1 = ts1_ - ts0_, d2 = ts2_ - ts1_;
+      for (int o = 32; o; o >>= 1) { const long long u1 = __shfl_xor(d1, o), u2 = __shfl_xor(d2, o); d1 = d1 > u1 ? d1 : u1; d2 = d2 > u2 ? d2 : u2; }
+      if (lane == 0) { V1B_ADD(34, d1); V1B_ADD(35, d2); V1B_ADD(36, V1B_NOW() - ts0_); V1B_ADD(tl ? (bm ? 37 : 38) : 39, d1); V1B_ADD(tl ? (bm ? 3 : 4) : 6, 1); }
       int mx = dbg_steps;
       for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(mx, o); mx = mx > t ? mx : t; }
       V1B_ADD(31, dbg_steps);
@@ -1335,19 +1445,19 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
   // no two nodes with the same one)
   int nvert = 0;
   for (int m = lane; m < nn; m += 64) {
-    const int cf = cntfl[m];
+    const int cf = cntfl.get(m);
     if (!(cf & 0x80)) continue;
-    const int nx = succ[m];
-    if (nx >= nn || !(v1_gl(cntfl + nx) & 0x80)) bad = 1;
-    else st[nx] = (unsigned short)m;
+    const int nx = succ.get(m);
+    if (nx >= nn || !(cntfl.get(nx) & 0x80)) bad = 1;
+    else st.set(nx, (unsigned short)m);
     nvert += cf & 0x3f;
   }
   v1_wave_sync();
   for (int m = lane; m < nn; m += 64)
-    if ((cntfl[m] & 0x80) && !bad && v1_gl(st + succ[m]) != m) bad = 1;
+    if ((cntfl.get(m) & 0x80) && !bad && st.get(succ.get(m)) != m) bad = 1;
   for (int o = 32; o; o >>= 1) nvert += __shfl_xor(nvert, o);
-  const int ms = (v1_gl(cntfl) & 0x80) ? 0 : 1;   // the outer border starts at the first pixel's west crack
-  if (nvert > 65535 || !(v1_gl(cntfl + ms) & 0x80)) bad = 1;
+  const int ms = (cntfl.get(0) & 0x80) ? 0 : 1;   // the outer border starts at the first pixel's west crack
+  if (nvert > 65535 || !(cntfl.get(ms) & 0x80)) bad = 1;
   bad = __any(bad);
   int nl = 1, total = 0, fbase = 0, cbase = 0;
   if (!bad) {
@@ -1357,11 +1467,11 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
     // east crack in raster order -- and the vertices emitted from itself up to there.  Updated in place: any mix of
     // old and new words is a valid pair of windows.
     for (int m = lane; m < nn; m += 64) {
-      const int cf = cntfl[m];
+      const int cf = cntfl.get(m);
       unsigned long long w = (unsigned long long)m | 0xffffull << 16;
       if (cf & 0x80) {
         const unsigned key = m == ms ? 0u : ((cf & 0x40) ? (unsigned)(m >> 1) + 1u : 0xffffu);
-        w = (unsigned long long)succ[m] | (unsigned long long)key << 16 | (unsigned long long)(cf & 0x3f) << 48;
+        w = (unsigned long long)succ.get(m) | (unsigned long long)key << 16 | (unsigned long long)(cf & 0x3f) << 48;
       }
       jw_st(m, w);
     }
@@ -1390,28 +1500,28 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
     }
     // the loop's first node
     for (int m = lane; m < nn; m += 64) {
-      if (!(cntfl[m] & 0x80)) continue;
+      if (!(cntfl.get(m) & 0x80)) continue;
       const unsigned key = (unsigned)(jw_ld(m) >> 16) & 0xffff;
       int s0 = ms;
       if (key == 0xffff) bad = 1;
-      else if (key) s0 = (v1_gl(cntfl + 2 * (key - 1) + 1) & 0x80) ? 2 * (key - 1) + 1 : 2 * (key - 1);
-      st[m] = (unsigned short)s0;
+      else if (key) s0 = (cntfl.get(2 * (key - 1) + 1) & 0x80) ? 2 * (key - 1) + 1 : 2 * (key - 1);
+      st.set(m, (unsigned short)s0);
     }
     v1_wave_sync();
     // number the loops (0 = outer, holes in node order), their vertex counts
     for (int mb = 0; mb < nn; mb += 64) {
       const int m = mb + lane;
-      const bool first = m < nn && (cntfl[m] & 0x80) && st[m] == m;
+      const bool first = m < nn && (cntfl.get(m) & 0x80) && st.get(m) == m;
       const bool hole = first && m != ms;
       const unsigned long long bal = __ballot(hole);
       if (first) {
         const int no = hole ? nl + __popcll(bal & ((1ull << lane) - 1ull)) : 0;
         const unsigned long long w = jw_ld(m);
-        const int nx = succ[m];
+        const int nx = succ.get(m);
         if ((w >> 32) & 0xffff) bad = 1;   // (the first node is the key's node: no vertices before it)
         if (no < V1F_LOOPS) {
-          loop[m] = (unsigned char)no;
-          ltab[no * 4] = (cntfl[m] & 0x3f) + (nx == m ? 0 : (int)((jw_ld(nx) >> 32) & 0xffff));
+          loop.set(m, (unsigned char)no);
+          ltab[no * 4] = (cntfl.get(m) & 0x3f) + (nx == m ? 0 : (int)((jw_ld(nx) >> 32) & 0xffff));
           ltab[no * 4 + 1] = (int)((w >> 16) & 0xffff) - 1;
         }
       }
@@ -1447,13 +1557,13 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
         cx.c_key[c] = 0ull;
       }
       if (lane == 0) *cx.overflow = 1;
-      for (int k = lane; k < np; k += 64) cx.mark[v1_gl(plist + k)] = 0;
+      for (int k = lane; k < np; k += 64) cx.mark[plist.get(k)] = 0;
       v1_wave_sync();
       return true;
     }
   }
   if (bad) {
-    for (int k = lane; k < np; k += 64) cx.mark[v1_gl(plist + k)] = 0;
+    for (int k = lane; k < np; k += 64) cx.mark[plist.get(k)] = 0;
     v1_wave_sync();
     if (lane == 0) V1B_ADD(18, 1);
     return false;
@@ -1462,23 +1572,23 @@ __device__ __forceinline__ bool v1_fast_blob(const V1Grid& g, V1Paint& pt, const
   [[maybe_unused]] const long long t3_ = V1B_NOW();
   // (5) vertices to their places (a lane reads back what it wrote itself), marks, contour entries
   for (int m = lane; m < nn; m += 64) {
-    const int cf = cntfl[m];
+    const int cf = cntfl.get(m);
     if (!(cf & 0x80)) continue;
-    const int s0 = st[m], l = v1_gl(loop + s0);
+    const int s0 = st.get(m), l = loop.get(s0);
     const int first = m == s0 ? 0 : ltab[l * 4] - (int)((jw_ld(m) >> 32) & 0xffff);
     short2* dst = cx.vpool + fbase + ltab[l * 4 + 2] + first;
     for (int k = 0; k < (cf & 0x3f); k++) dst[k] = tmp[m * V1F_K + k];
   }
   for (int k = lane; k < np; k += 64) {
-    const int e = v1_gl(cntfl + 2 * k + 1), w = v1_gl(cntfl + 2 * k);
+    const int e = cntfl.get(2 * k + 1), w = cntfl.get(2 * k);
     int l = -1;
-    if (e & 0x80) l = v1_gl(loop + v1_gl(st + 2 * k + 1));
-    else if ((w & 0xc0) == 0xc0) l = v1_gl(loop + v1_gl(st + 2 * k));
-    cx.mark[v1_gl(plist + k)] = (unsigned short)(l < 0 ? 0 : (l == 0 ? i : cbase + l - 1) + 1);
+    if (e & 0x80) l = loop.get(st.get(2 * k + 1));
+    else if ((w & 0xc0) == 0xc0) l = loop.get(st.get(2 * k));
+    cx.mark[plist.get(k)] = (unsigned short)(l < 0 ? 0 : (l == 0 ? i : cbase + l - 1) + 1);
   }
   for (int l = 1 + lane; l < nl; l += 64) {
     const int c = cbase + l - 1, k = ltab[l * 4 + 1];
-    cx.c_disc[c] = (int)v1_gl(prow + k) * cx.W + srun[v1_gl(plist + k)].y;
+    cx.c_disc[c] = (int)prow.get(k) * cx.W + srun[plist.get(k)].y;
     cx.c_par[c] = (short)i;
     cx.c_link[c] = -1;
     cx.c_hole[c] = 1;

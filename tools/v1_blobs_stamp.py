@@ -15,7 +15,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 eng = Engine(0)
 bp, pp = get_body_parts_and_pose_pairs("COCO")
 eng.set_net_out(np.stack([synth.synth_net_output(2000 * P + i, P, COCO_18, 46, 82) for i in range(B)]))
-L = _ffi.lib(); cyc = (ctypes.c_ulonglong * 32)()
+L = _ffi.lib(); cyc = (ctypes.c_ulonglong * 40)()
 for _ in range(3):
     eng.decode_v1(bp, pp, MAPIDX, B, 1920, 1080, 0.1, kp_cap=256, person_cap=1024)
 if not hasattr(L, "ph_debug_v1_blobs"):      # a build without the stamps: kernel times only (median of 9)
@@ -47,3 +47,6 @@ print(f"fast path: {cyc[16]} blobs done, {cyc[17]} without table space, {cyc[18]
 print(f"setup, cycles per block from the kernel's start: pieces scattered {cyc[27] / nb:.0f}, rows sorted {cyc[28] / nb:.0f}, "
       f"unions {cyc[29] / nb:.0f}, roots {cyc[30] / nb:.0f}, walks start {cyc[7] / nb:.0f}")
 print(f"segments: {cyc[31] / max(1, cyc[16]):.0f} steps per blob over all lanes, {cyc[13] / max(1, cyc[16]):.0f} = the sum over a blob's rounds of the longest segment")
+print(f"tables in LDS for {cyc[33]} blobs, a bitmap for {cyc[32]}")
+print(f"segment rounds, cycles per blob: longest node set-up {cyc[34] / nf:.0f}, longest step loop {cyc[35] / nf:.0f}, whole rounds {cyc[36] / nf:.0f}")
+print(f"node set-up per round: bitmap blobs {cyc[37] / max(1, cyc[3]):.0f} cycles ({cyc[3]} rounds), LDS tables without bitmap {cyc[38] / max(1, cyc[4]):.0f} ({cyc[4]}), tables in the pool {cyc[39] / max(1, cyc[6]):.0f} ({cyc[6]})")
