@@ -2194,55 +2194,54 @@ __global__ __launch_bounds__(64) void v1_assemble_kernel(V1Model mdl, int kp_cap
     while (p + 1 < mdl.n_parts && id >= s_off[p + 1]) p++;
     return (double)kps[((size_t)b * mdl.n_parts + p) * kp_cap * 3 + (id - s_off[p]) * 3 + 2];
   };
-  // The connections of a limb are consumed one after the other (each may extend the row the previous one made), but
-  // what a step needs from global memory -- the pair, its score, the two keypoint scores -- does not depend on the
-  // rows: 64 connections at a time are fetched by the 64 lanes into LDS, and the serial loop reads them from there.
-  __shared__ double s_conn[64 * 5];   // partA, partB, score, keypoint score of A, of B
+  // The reference consumes the connections of a limb one after the other, but within one limb they do not depend on
+  // each other: a connection looks for the FIRST row whose part-A slot holds its A keypoint, the A keypoints of a
+  // limb's connections are all different (getValidPairs keeps one B per A), this limb only writes the part-B slot
+  // and the score (at most once per row), and a row it appends holds an A no other connection has.  So 64
+  // connections at a time: every lane scans the rows for its own A (the same row entry for all lanes: one broadcast
+  // read per row), the hits update their rows, the misses append theirs in connection order (ballot prefix).
   for (int k = 0; k < mdl.n_limbs; k++) {
     const int nc = n_pairs[(size_t)b * mdl.n_limbs + k];
     if (nc < 0) continue;  // invalid pair
     const int ia = mdl.pair_parts[2 * k], ib = mdl.pair_parts[2 * k + 1];
     const double* vp = pairs + ((size_t)b * mdl.n_limbs + k) * kp_cap * 3;
     for (int i0 = 0; i0 < nc; i0 += 64) {
-      __syncthreads();   // the previous chunk has been consumed
-      if (i0 + lane < nc) {
-        const double a = vp[(i0 + lane) * 3], bq = vp[(i0 + lane) * 3 + 1];
-        s_conn[lane * 5] = a;
-        s_conn[lane * 5 + 1] = bq;
-        s_conn[lane * 5 + 2] = vp[(i0 + lane) * 3 + 2];
-        s_conn[lane * 5 + 3] = kp_score((int)a);
-        s_conn[lane * 5 + 4] = kp_score((int)bq);
+      const bool act = i0 + lane < nc;
+      double partA = -2.0, partB = 0.0, sc = 0.0, ka = 0.0, kb = 0.0;
+      if (act) {
+        partA = vp[(i0 + lane) * 3];
+        partB = vp[(i0 + lane) * 3 + 1];
+        sc = vp[(i0 + lane) * 3 + 2];
+        ka = kp_score((int)partA);
+        kb = kp_score((int)partB);
       }
+      const int n = s_n;
+      int hit = -1;
+      for (int r = 0; r < n; r++) {
+        const double v = rows[r * RW + ia];
+        if (hit < 0 && v == partA) hit = r;
+      }
+      const bool create = act && hit < 0 && k < mdl.n_parts + 1 - 2;
+      const unsigned long long bal = __ballot(create);
+      const int idx = n + __popcll(bal & ((1ull << lane) - 1ull)), total = __popcll(bal);
+      if (act && hit >= 0) {
+        rows[hit * RW + ib] = partB;
+        rows[hit * RW + RW - 1] = rows[hit * RW + RW - 1] + (kb + sc);
+      }
+      if (create) {
+        if (idx < person_cap) {
+          double* row = rows + idx * RW;
+          for (int q = 0; q < RW; q++) row[q] = -1.0;
+          row[ia] = partA;
+          row[ib] = partB;
+          row[RW - 1] = (ka + kb) + sc;
+        } else {
+          *overflow = 1;
+        }
+      }
+      __syncthreads();   // (one wave: orders the LDS writes above before the next chunk's reads)
+      if (lane == 0) s_n = n + total < person_cap ? n + total : person_cap;
       __syncthreads();
-      const int cnt = nc - i0 < 64 ? nc - i0 : 64;
-      for (int i = 0; i < cnt; i++) {
-        const double partA = s_conn[i * 5], partB = s_conn[i * 5 + 1], sc = s_conn[i * 5 + 2];
-        const int n = s_n;
-        int hit = -1;
-        for (int r0 = 0; r0 < n && hit < 0; r0 += 64) {
-          const int r = r0 + lane;
-          const unsigned long long m = __ballot(r < n && rows[r * RW + ia] == partA);
-          if (m) hit = r0 + __ffsll((long long)m) - 1;
-        }
-        if (lane == 0) {
-          if (hit >= 0) {
-            rows[hit * RW + ib] = partB;
-            rows[hit * RW + RW - 1] = rows[hit * RW + RW - 1] + (s_conn[i * 5 + 4] + sc);
-          } else if (k < mdl.n_parts + 1 - 2) {
-            if (n < person_cap) {
-              double* row = rows + n * RW;
-              for (int q = 0; q < RW; q++) row[q] = -1.0;
-              row[ia] = partA;
-              row[ib] = partB;
-              row[RW - 1] = (s_conn[i * 5 + 3] + s_conn[i * 5 + 4]) + sc;
-              s_n = n + 1;
-            } else {
-              *overflow = 1;
-            }
-          }
-        }
-        __syncthreads();
-      }
     }
   }
   const int n = s_n;
