@@ -119,6 +119,35 @@ def test_random_sizes_and_ratios(engine, seed, connector):
         _check_frame(kp_o, sc_o, inter, got, extras, b, BODY_25, engine)
 
 
+def test_non_finite_heat_maps_take_the_nan_aware_rows(engine):
+    # nms_detect_cols_kernel walks planes whose values are all finite and < 1e30 without NaN bookkeeping; a plane with
+    # a NaN, an infinity or a value whose cubic overflows takes the other loop body, where `v > NaN` is false in each
+    # of the eight neighbour tests as in the oracle's array comparisons.  Other planes of the same frame stay fast.
+    from oracle import decode_v2
+    f = np.stack([synth.synth_net_output(21, 3, BODY_25, 46, 82), synth.synth_net_output(22, 2, BODY_25, 46, 82)])
+    f[0, 0, 10, 20] = np.nan
+    f[0, 1, 5, 5] = np.inf
+    f[0, 2, 30, 60] = -np.inf
+    f[0, 3, 20, 40] = 3e38          # finite, but the cubic of it overflows: inf - inf further on
+    f[0, 4, 0, 0] = np.nan          # corner: clamped taps spread it over the border rows
+    f[1, 7, 45, 81] = 2e30          # finite and harmless, still above the fast path's bound
+    engine.set_net_out(f)
+    got, extras = engine.decode_v2(BODY_25, 2, 368, 656, want_peaks=True)
+    for b in range(2):
+        with np.errstate(all="ignore"):
+            up = decode_v2.upsample_bicubic(f[b, :BODY_25.n_parts], 368, 656)
+            want = decode_v2.nms(up, BODY_25.nms_threshold, BODY_25.max_peaks)
+        np.testing.assert_array_equal(extras["peaks"][b, :, 0, 0], want[:, 0, 0])
+        for p in range(BODY_25.n_parts):
+            n = int(want[p, 0, 0])
+            # integer peak locations and scores (the refined centroid of a peak next to a NaN is a NaN on both sides)
+            np.testing.assert_array_equal(extras["peaks"][b, p, 1:n + 1, 2].view(np.uint32),
+                                          want[p, 1:n + 1, 2].view(np.uint32))
+            ok = ~np.isnan(want[p, 1:n + 1, 0])
+            np.testing.assert_array_equal(extras["peaks"][b, p, 1:n + 1, :2][ok], want[p, 1:n + 1, :2][ok])
+    assert extras["peaks"][:, :, 0, 0].sum() > 0
+
+
 def test_empty_and_flat_maps(engine):
     z = np.zeros((2, BODY_25.n_channels, 46, 82), np.float32)
     z[1] = 0.5                                   # plateau: strict > never fires
