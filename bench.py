@@ -57,8 +57,8 @@ def cpu_baseline(net, weights, model, n_frames, seed):
 
 VALU_LANE_OPS_PER_S = 256 * 64 * 2.4e9    # 256 CUs x 64 lanes x 2.4 GHz: one fp32 VALU operation per lane and clock
 # VALU instructions the NMS kernel issues per upsampled pixel, measured: SQ_INSTS_VALU x 64 lanes / pixels
-# (profiles/r03_pmc_nms_insts.txt: 106.3 M wave instructions per 32-frame launch; a packed fp32 instruction counts once)
-NMS_OPS_PER_PIXEL = 35
+# (profiles/r03_pmc_nms_insts.txt: 88.2 M wave instructions per 32-frame launch; a packed fp32 instruction counts once)
+NMS_OPS_PER_PIXEL = 29
 
 
 def tail_block(B, src_h, src_w, pre_ms, decode_ms, paf_pairs):

@@ -53,9 +53,10 @@ __device__ __forceinline__ float lane_right(float v) {
 // (key_cnt = -1) and leaves it to the !FAST instantiation, launched right after on the same stream, whose blocks
 // return at once unless their stripe carries that mark.  (One kernel with both bodies: 88 instead of 60 registers
 // at G = 2 and 0.34 instead of 0.29 ms per 32 frames with the refine kernel; as two kernels, the fast one held to 64
-// registers: 0.27 ms.  The row body is now 29 VALU instructions for two pixels, 9 of them packed; SQ_INSTS_VALU says
-// the kernel issues 60 per row body -- the rest is load_taps (one new source row and the cubic's a, b, c per column
-// group every `scale` rows, behind chains of uniform branches) and the copies at the loop's joins.)
+// registers: 0.27 ms.  The row body is now 29 VALU instructions for two pixels, 9 of them packed; SQ_INSTS_VALU said
+// the kernel issued 60 per row body -- the rest was load_taps (the source rows of the next `scale` output rows and
+// the cubic's a, b, c per column group, behind chains of uniform branches) and the copies at the loop's joins; with
+// the window of source rows moved on by one in the usual case instead of searched: 50, 0.25 ms.)
 template <int G, bool FAST>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(G == 4 ? 4 : 8))) void nms_detect_cols_kernel(const float* __restrict__ net_out, int C, int hs, int ws,
                                                                int Ht, int Wt, float threshold, int max_peaks,
@@ -143,16 +144,25 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(G == 4 ? 4
     const TapsP ty = s_yt[i];
     const int n0 = __builtin_amdgcn_readfirstlane((int)ty.i0), n1 = __builtin_amdgcn_readfirstlane((int)ty.i1);
     const int n2 = __builtin_amdgcn_readfirstlane((int)ty.i2), n3 = __builtin_amdgcn_readfirstlane((int)ty.i3);
+    // the usual step down the image: the window of source rows moves on by one (its last row may repeat at the
+    // bottom edge) -- one new interpolated row per column group, no search through the rows held
+    const bool shift = n0 == ti1 && n1 == ti2 && n2 == ti3;
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      auto pick = [&](int nk) -> float {
-        if (nk == ti0) return tv[g][0];
-        if (nk == ti1) return tv[g][1];
-        if (nk == ti2) return tv[g][2];
-        if (nk == ti3) return tv[g][3];
-        return cubic_row(s_src + nk * ws, tx[g]);
-      };
-      const float v0 = pick(n0), v1 = pick(n1), v2 = pick(n2), v3 = pick(n3);
+      float v0, v1, v2, v3;
+      if (shift) {
+        v0 = tv[g][1]; v1 = tv[g][2]; v2 = tv[g][3];
+        v3 = n3 == ti3 ? tv[g][3] : cubic_row(s_src + n3 * ws, tx[g]);
+      } else {
+        auto pick = [&](int nk) -> float {
+          if (nk == ti0) return tv[g][0];
+          if (nk == ti1) return tv[g][1];
+          if (nk == ti2) return tv[g][2];
+          if (nk == ti3) return tv[g][3];
+          return cubic_row(s_src + nk * ws, tx[g]);
+        };
+        v0 = pick(n0); v1 = pick(n1); v2 = pick(n2); v3 = pick(n3);
+      }
       tv[g][0] = v0; tv[g][1] = v1; tv[g][2] = v2; tv[g][3] = v3;
       ca[g] = (((-0.5f * v0 + 1.5f * v1) - 1.5f * v2) + 0.5f * v3);   // cubic()'s a, b, c
       cb[g] = (((v0 - 2.5f * v1) + 2.0f * v2) - 0.5f * v3);
