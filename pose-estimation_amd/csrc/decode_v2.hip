@@ -378,14 +378,26 @@ __device__ __forceinline__ float4 cubic_coef(const float* __restrict__ row, int 
   q.w = v1;
   return q;
 }
-__device__ __forceinline__ float cubic_row_cf(const float4* row, int i1, float d) {
-  const float4 q = row[i1];
-  return ((((q.x * d) * d) * d + (q.y * d) * d) - q.z * d) + q.w;
+// The two PAF planes of a limb are sampled at the same point, so their tables are kept INTERLEAVED -- 32 B per source
+// pixel: {a_x, a_y, b_x, b_y}, {c_x, c_y, v1_x, v1_y} -- and both planes go through cubic()'s operations as 2-vectors
+// (packed fp32 multiplies and adds: each element sees the same IEEE operations in the same order as cubic_row() / cubic() on one plane).
+typedef float paf_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ paf_f2 cubic_row_cf2(const float4* row, int i1, paf_f2 d) {
+  const float4 q0 = row[2 * i1], q1 = row[2 * i1 + 1];
+  const paf_f2 a = {q0.x, q0.y}, b = {q0.z, q0.w}, c = {q1.x, q1.y}, v1 = {q1.z, q1.w};
+  return ((((a * d) * d) * d + (b * d) * d) - c * d) + v1;
 }
-__device__ __forceinline__ float bicubic_cf(const float4* tab, int ws, const TapsP& tx, const TapsP& ty) {
-  const float t0 = cubic_row_cf(tab + ty.i0 * ws, tx.i1, tx.d), t1 = cubic_row_cf(tab + ty.i1 * ws, tx.i1, tx.d);
-  const float t2 = cubic_row_cf(tab + ty.i2 * ws, tx.i1, tx.d), t3 = cubic_row_cf(tab + ty.i3 * ws, tx.i1, tx.d);
-  return cubic(t0, t1, t2, t3, ty.d);
+__device__ __forceinline__ paf_f2 cubic2(paf_f2 v0, paf_f2 v1, paf_f2 v2, paf_f2 v3, paf_f2 d) {
+  const paf_f2 a = (((-0.5f * v0 + 1.5f * v1) - 1.5f * v2) + 0.5f * v3);
+  const paf_f2 b = (((v0 - 2.5f * v1) + 2.0f * v2) - 0.5f * v3);
+  const paf_f2 c = 0.5f * (v0 - v2);
+  return ((((a * d) * d) * d + (b * d) * d) - c * d) + v1;
+}
+__device__ __forceinline__ paf_f2 bicubic_cf2(const float4* tab, int ws, const TapsP& tx, const TapsP& ty) {
+  const paf_f2 dx = {tx.d, tx.d}, dy = {ty.d, ty.d};
+  const paf_f2 t0 = cubic_row_cf2(tab + 2 * (ty.i0 * ws), tx.i1, dx), t1 = cubic_row_cf2(tab + 2 * (ty.i1 * ws), tx.i1, dx);
+  const paf_f2 t2 = cubic_row_cf2(tab + 2 * (ty.i2 * ws), tx.i1, dx), t3 = cubic_row_cf2(tab + 2 * (ty.i3 * ws), tx.i1, dx);
+  return cubic2(t0, t1, t2, t3, dy);
 }
 
 // COEF: mapx / mapy are float4 coefficient tables (above), else the raw planes.
@@ -424,8 +436,15 @@ __device__ float score_ab(const float* A, const float* Bp, const void* mapx, con
       my = my > Ht - 1 ? Ht - 1 : my;
       my = my < 0 ? 0 : my;
       const TapsP tx = xt[mx], ty = yt[my];
-      const float px = COEF ? bicubic_cf((const float4*)mapx, ws, tx, ty) : bicubic_tp((const float*)mapx, ws, tx, ty);
-      const float py = COEF ? bicubic_cf((const float4*)mapy, ws, tx, ty) : bicubic_tp((const float*)mapy, ws, tx, ty);
+      float px, py;
+      if constexpr (COEF) {   // mapx = the interleaved table of both planes
+        const paf_f2 pxy = bicubic_cf2((const float4*)mapx, ws, tx, ty);
+        px = pxy.x;
+        py = pxy.y;
+      } else {
+        px = bicubic_tp((const float*)mapx, ws, tx, ty);
+        py = bicubic_tp((const float*)mapy, ws, tx, ty);
+      }
       const float s = nx * px + ny * py;
       if (s > inter_thr) {
         total = total + s;
@@ -475,8 +494,9 @@ __global__ __launch_bounds__(PAF_THREADS) void paf_score_kernel(const float* __r
   for (int i = tid; i < hs * ws; i += PAF_THREADS) {
     if (COEF) {
       const int r = i / ws, c = i - r * ws;
-      ((float4*)s_mx)[i] = cubic_coef(px + r * ws, c, ws);
-      ((float4*)s_my)[i] = cubic_coef(py + r * ws, c, ws);
+      const float4 qx = cubic_coef(px + r * ws, c, ws), qy = cubic_coef(py + r * ws, c, ws);
+      ((float4*)s_mx)[2 * i] = make_float4(qx.x, qy.x, qx.y, qy.y);       // (s_my follows s_mx: one 32-B entry per pixel)
+      ((float4*)s_mx)[2 * i + 1] = make_float4(qx.z, qy.z, qx.w, qy.w);
     } else {
       s_mx[i] = px[i];
       s_my[i] = py[i];
