@@ -93,6 +93,7 @@ struct Op {
   float* slope = nullptr;
   double flops = 0.0;  // algorithmic, per frame
   bool skip = false;   // computed inside the next op's kernel (stem fusion)
+  int cin_span = 0;    // conv: 1 + the last input channel read that carries data (cin_map >= 0)
   int* tile_ctr = nullptr;  // stem op: the persistent kernel's two tile counters
   // 1x1 pair (conv_pair.hip): `pair_head` is computed inside the next op's kernel and `pair` runs that kernel
   // whenever ph_pair_enabled(); both keep their own parameters for the separate launches
@@ -514,7 +515,10 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       }
     }
     int real_cin = 0;
-    for (int cc = 0; cc < d.cin_read; cc++) real_cin += d.cin_map[cc] >= 0;
+    for (int cc = 0; cc < d.cin_read; cc++) {
+      real_cin += d.cin_map[cc] >= 0;
+      if (d.cin_map[cc] >= 0) o.cin_span = cc + 1;
+    }
     o.flops = 2.0 * d.kh * d.kw * real_cin * d.cout * in.d.height * in.d.width;
     // descriptor pointers are host memory owned by the caller: do not keep them
     o.d.weight = nullptr;
@@ -547,6 +551,7 @@ static int net_build(ph_ctx* c, int batch, const ph_buf_desc* bufs, int n_bufs, 
       q.bias0 = a.bias;
       q.Kpad0 = a.cp.Kpad;
       q.act0 = a.d.act;
+      q.cin0_span = a.cin_span;
       q.in = fb.ptr;
       q.in_Hp = fb.Hp();
       q.in_Wp = fb.Wp();

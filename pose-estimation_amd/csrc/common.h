@@ -42,6 +42,7 @@ struct PhConvParams {
   const bf16* wt0;       // [64][Kpad0] producer weights, k = tap*8 + c
   const float* bias0;    // [64]
   int Kpad0, act0;       // act0: 0 none, 1 ReLU
+  int cin0_span;         // 1 + the last channel of the 8-channel buffer that the producer's weights use
   int* tile_ctr;         // persistent stem kernel (conv_stem.hip): two tile counters, used alternately per launch
   int tile_par;          //   which of the two this launch counts on (the kernel zeroes the other one)
   int pool;              // 1: 2x2/2 max pool fused into the epilogue (dst = pooled geometry), mode 1 only

@@ -15,11 +15,12 @@
 //     8 fragment reads per 16 MFMAs (half the LDS read rate at full MFMA rate), and the 2x2 pool stays inside the
 //     wave (row pairs in one lane's registers, column pairs in neighbouring lanes);
 //   * the 18 x 34 x 64-channel input patch of conv1_2 is computed by conv1_1 straight into LDS (never in memory),
-//     from frame pixels the lanes read directly from global memory into MFMA fragments -- no frame patch in LDS;
-//     the next tile's frame pixels are requested before the K loop of the current tile starts;
+//     from the 20 x 36 frame pixels under it, staged in LDS once per tile (channels 0..3, 5.8 KB): the next tile's
+//     are requested before the K loop of the current tile starts and written to LDS after it;
 //   * the K loop (18 steps of 16 MFMAs per wave) has no barrier and no global load: two barriers per tile in all
 //     (patch complete / patch free).
-// LDS: patch 2 x 41,472 B (two 32-channel planes, rows 36 pixels apart) + weights 73,728 B + bias/slope = 157 KB.
+// LDS: patch 2 x 41,472 B (two 32-channel planes, rows 36 pixels apart) + weights 73,728 B + bias/slope + frame
+// pixels 5,760 B = 159.4 KB of the CU's 160.
 // Accumulation order per output = the halo kernel's (chunk-major, taps inside), so results are bit-identical to it.
 #include "common.h"
 #include <type_traits>
@@ -35,7 +36,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define ST_PLANE ((ST_TH + 2) * ST_PW * 64)   // 41,472 B per 32-channel plane
 #define ST_WBYTES (18 * 4096)          // 18 (tap, chunk) slices of 64 channels x 64 B
 #define ST_SROW 144                    // staged pooled pixel: 64 channels bf16 + 16 B (bank spread)
-#define ST_LDS (2 * ST_PLANE + ST_WBYTES + 3 * 256 + 16)
+#define ST_FH (ST_TH + 4)              // frame pixels under the patch: 20 rows ..
+#define ST_FW (ST_TW + 4)              // .. x 36 columns
+#define ST_FBYTES (ST_FH * ST_FW * 8)  // 5,760 B: channels 0..3 (8 bytes) of each
+#define ST_LDS (2 * ST_PLANE + ST_WBYTES + 3 * 256 + 16 + ST_FBYTES)
 
 #ifdef ST_STAMP
 // Diagnostic build only (tools/stem512_stamp.py): cycles per phase, summed over the tiles of every block's wave 1.
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
   float* const s_slope = s_bias + 64;
   float* const s_bias0 = s_slope + 64;
   int* const s_tn = (int*)(s_bias0 + 64);
+  char* const fpl = (char*)(s_tn + 4);   // the tile's frame pixels, channels 0..3: [ST_FH][ST_FW] x 8 B
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -97,9 +102,9 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
     if (blockIdx.x == 0) p.tile_ctr[p.tile_par ^ 1] = 0;  // the next launch's counter (this stream runs them in order)
     s_tn[0] = (int)gridDim.x + atomicAdd(ctr, 1);
   }
-  // conv1_1 weights: 4 channel blocks x 3 K steps (K = 9 taps x 8 channels, padded to 96 with zero rows).  48
-  // registers that would otherwise be held across the K loop, where the accumulators and the next tile's frame pixels
-  // already fill the file: they are fetched again (12 KB, L1 / L2 resident) while each tile's pooled rows go out.
+  // conv1_1 weights: 4 channel blocks x 3 K steps (K = 9 taps x 8 channels, padded to 96 with zero rows): 48
+  // registers, held for the life of the block now that the frame pixels no longer wait in 60 registers across the K
+  // loop (they were fetched again for every tile before: 12 more vector-memory instructions per wave and tile).
   bf16x8 wf[4][3];
   auto load_wf = [&]() {
 #pragma unroll
@@ -133,11 +138,13 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
   char* const stg = lds + ((80 * wave / ST_PC) * ST_PW + (80 * wave) % ST_PC) * 64;
 
   const int tiles_per_image = tiles_x * tiles_y;
-  bf16x8 xf[5][3];
-#pragma unroll
-  for (int u = 0; u < 5; u++)
-#pragma unroll
-    for (int e = 0; e < 8; e++) xf[u][2][e] = (bf16)0.f;  // (lanes that never load K step 2 multiply zeros by zero weights)
+  // The frame pixels under a tile's patch (20 x 36, the first four of their 8 channels: ph_stem512_applies) come
+  // into LDS ONCE per tile -- two 8-byte loads per lane, requested before the K loop of the previous tile, written
+  // to `fpl` after it -- and conv1_1's fragments are read from there.  (Round 3's first form read every tap of every
+  // patch pixel from global memory straight into the fragments: 15 scattered 16-byte loads per lane and tile, issued
+  // by all 8 waves at once -- 4.6 thousand cycles of a tile's 24.5 thousand went into issuing them, whatever their
+  // size: the CU's vector-memory instruction rate, not its bytes)
+  bf16x4 fpx[2];
   int nx_b = 0, nx_y0 = 0, nx_x0 = 0;  // image and origin of the tile whose frame pixels were requested last
   auto issue_loads = [&](int t) {
     const int b = t / tiles_per_image;
@@ -148,28 +155,34 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
     nx_x0 = tx * ST_TW;
     // frame pixel under tap (0,0) of patch pixel (0,0): image (ty*16 - 2, tx*32 - 2)
     const int Q0 = (b * Hp + ty * ST_TH - 2 + pi) * Wp + tx * ST_TW - 2 + pi;
-    int toff[3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ks++) {
-      int tp = ks * 4 + fq;
-      tp = tp < 8 ? tp : 8;  // taps 9..11 carry zero weights: read any finite pixel
-      const int th = (tp * 11) >> 5;  // tp / 3 for tp <= 8
-      toff[ks] = th * Wp + (tp - th * 3);
-    }
-#pragma unroll
-    for (int u = 0; u < 5; u++) {
-      int r, c;
-      patch_rc(u, r, c);
-      const int rel = r * Wp + c;
-#pragma unroll
-      for (int ks = 0; ks < 3; ks++) {
-        int Q = Q0 + rel + toff[ks];
-        Q = Q < 0 ? 0 : (Q < p.NQ ? Q : p.NQ - 1);
-        // K step 2 = taps 8..11, of which only tap 8 (the lanes with fq == 0) has weights: a quarter of the lanes load
-        if (ks < 2 || fq == 0) xf[u][ks] = *(const bf16x8*)((const char*)p.in + (size_t)(unsigned)Q * 16u);
-      }
+    for (int q = 0; q < 2; q++) {
+      int idx = tid + q * 512;
+      idx = idx < ST_FH * ST_FW ? idx : ST_FH * ST_FW - 1;   // (past the last pixel: it again, no lane switched off)
+      const int fy = (int)(((unsigned)idx * 1821u) >> 16);   // idx / 36 for idx < 720
+      int Q = Q0 + fy * Wp + (idx - fy * ST_FW);
+      Q = Q < 0 ? 0 : (Q < p.NQ ? Q : p.NQ - 1);
+      fpx[q] = *(const bf16x4*)((const char*)p.in + (size_t)(unsigned)Q * 16u);
     }
   };
+  auto store_frame = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      int idx = tid + q * 512;
+      idx = idx < ST_FH * ST_FW ? idx : ST_FH * ST_FW - 1;
+      *(bf16x4*)(fpl + idx * 8) = fpx[q];
+    }
+  };
+  // conv1_1's operand of K step ks for this lane: K group fq of 8 = the 8 channels of tap ks * 4 + fq, of which
+  // 4..7 are the frame buffer's padding (zero); taps 9..11 carry zero weights: any finite pixel serves
+  int ftap[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ks++) {
+    int tp = ks * 4 + fq;
+    tp = tp < 8 ? tp : 8;
+    const int th = (tp * 11) >> 5;  // tp / 3 for tp <= 8
+    ftap[ks] = (th * ST_FW + (tp - th * 3)) * 8;
+  }
 
   // pooled rows of the previous tile, stored one phase later (see P3)
   u32x4 pend[2];
@@ -193,9 +206,13 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
     }
   };
 
+#ifdef ST_STAMP
+  long long sacc_[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   int t = blockIdx.x;
-  issue_loads(t);
-  __syncthreads();  // weights, biases and s_tn[0] are in LDS
+  issue_loads(t < ntiles ? t : ntiles - 1);
+  store_frame();
+  __syncthreads();  // weights, biases, s_tn[0] and the first tile's frame pixels are in LDS
   int it = 0;
   while (t < ntiles) {
     const int tb = nx_b, ty0 = nx_y0, tx0 = nx_x0;  // (computed when this tile's frame pixels were requested)
@@ -224,10 +241,18 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
         f32x4 a0[4];
 #pragma unroll
         for (int nb = 0; nb < 4; nb++) a0[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x4 zero4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) zero4[e] = (bf16)0.f;
+        const char* const fsrc = fpl + (r * ST_FW + c) * 8;
+        bf16x8 xf[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++)
+          xf[ks] = __builtin_shufflevector(*(const bf16x4*)(fsrc + ftap[ks]), zero4, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int ks = 0; ks < 3; ks++)   // four independent accumulation chains
 #pragma unroll
-          for (int nb = 0; nb < 4; nb++) a0[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], xf[u][ks], a0[nb], 0, 0, 0);
+          for (int nb = 0; nb < 4; nb++) a0[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], xf[ks], a0[nb], 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < 4; nb++) {
           bf16x4 o;
@@ -245,18 +270,20 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
 #endif
       }
     }
-    flush_rows();  // the previous tile's pooled rows (none before the first tile: pend_row is out of range)
+    // ---- the next tile: its number came in during the previous tile, its frame pixels travel during this K loop and
+    // are written to LDS after it.  The tile after that is asked for FIRST, while this wave has no other memory
+    // operation in flight: the compiler waits for everything outstanding where the counter's answer is consumed
+    const int tn = __builtin_amdgcn_readfirstlane(s_tn[it & 1]);
+    int tnn = ntiles;
+    if (tid == 0 && tn < ntiles) tnn = (int)gridDim.x + atomicAdd(ctr, 1);
 #ifdef ST_STAMP
     su_[2] = __builtin_readcyclecounter();
 #endif
-    // ---- the next tile: its number came in during the previous tile, its frame pixels travel during this K loop
-    const int tn = __builtin_amdgcn_readfirstlane(s_tn[it & 1]);
+    flush_rows();  // the previous tile's pooled rows (none before the first tile: pend_row is out of range)
 #ifdef ST_STAMP
     su_[3] = __builtin_readcyclecounter();
 #endif
-    issue_loads(tn < ntiles ? tn : ntiles - 1);  // (past the last tile: a harmless repeat, no branch around 15 loads)
-    int tnn = ntiles;
-    if (tid == 0 && tn < ntiles) tnn = (int)gridDim.x + atomicAdd(ctr, 1);
+    issue_loads(tn < ntiles ? tn : ntiles - 1);  // (past the last tile: a harmless repeat, no branch around the loads)
     ST_T(c1_);
     __syncthreads();  // A: the patch is complete
     ST_T(c2_);
@@ -293,6 +320,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    store_frame();  // the next tile's frame pixels (every wave left P1, the last reader of `fpl`, before barrier A)
     if (tid == 0) s_tn[(it + 1) & 1] = tnn;
     ST_T(c3_);
     __syncthreads();  // B: every wave has read the patch for the last time
@@ -300,7 +328,6 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
 
     // ---- P3: bias + activation, 2x2 max pool inside the wave, rows out through this wave's own LDS strip ---------
     // acc[i][j][e]: image row ty0 + 2 wave + (i >> 1), column tx0 + (i & 1) * 16 + fr, channel j * 16 + fq * 4 + e
-    load_wf();
     f32x4 bv[4], sv[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -361,25 +388,30 @@ __global__ __launch_bounds__(512, 1) void conv_stem512_kernel(const PhConvParams
     pend_col0 = tx0 >> 1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is read before P1 of the next tile rewrites it
 #ifdef ST_STAMP
-    if (lane == 0 && wave == 1) {
+    {  // summed in registers, written once after the last tile: an atomic per phase and tile sat in the in-order memory
+       // counter in front of the next tile's frame pixels
       const long long c5_ = __builtin_readcyclecounter();
-      atomicAdd(&st_dbg[0], (unsigned long long)(c1_ - c0_));   // P1 (waits for the frame pixels included) + next loads issued
-      atomicAdd(&st_dbg[1], (unsigned long long)(c2_ - c1_));   // barrier A
-      atomicAdd(&st_dbg[2], (unsigned long long)(c3_ - c2_));   // P2: K loop
-      atomicAdd(&st_dbg[3], (unsigned long long)(c4_ - c3_));   // barrier B
-      atomicAdd(&st_dbg[4], (unsigned long long)(c5_ - c4_));   // P3
-      atomicAdd(&st_dbg[5], 1ull);
-      atomicAdd(&st_dbg[6], (unsigned long long)(su_[0] - c0_));   // P1: up to the end of row block 0 (waits for loads)
-      atomicAdd(&st_dbg[7], (unsigned long long)(su_[1] - su_[0])); // P1: row blocks 1..4
-      atomicAdd(&st_dbg[8], (unsigned long long)(su_[2] - su_[1]));  // previous tile's rows stored
-      atomicAdd(&st_dbg[9], (unsigned long long)(su_[3] - su_[2]));  // next tile number from LDS
-      atomicAdd(&st_dbg[10], (unsigned long long)(c1_ - su_[3]));    // address arithmetic, 15 loads issued
+      sacc_[0] += c1_ - c0_;        // P1 (frame pixels from LDS) + previous rows stored + next loads issued
+      sacc_[1] += c2_ - c1_;        // barrier A
+      sacc_[2] += c3_ - c2_;        // P2: K loop (+ the next tile's frame pixels written to LDS)
+      sacc_[3] += c4_ - c3_;        // barrier B
+      sacc_[4] += c5_ - c4_;        // P3
+      sacc_[5] += 1;
+      sacc_[6] += su_[0] - c0_;     // P1: up to the end of row block 0
+      sacc_[7] += su_[1] - su_[0];  // P1: row blocks 1..4
+      sacc_[8] += su_[2] - su_[1];  // next tile number from LDS, the one after from the counter
+      sacc_[9] += su_[3] - su_[2];  // previous tile's rows stored
+      sacc_[10] += c1_ - su_[3];    // address arithmetic, next tile's loads issued
     }
 #endif
     t = tn;
     it++;
   }
   flush_rows();
+#ifdef ST_STAMP
+  if (lane == 0 && wave == 1)
+    for (int q = 0; q < 11; q++) atomicAdd(&st_dbg[q], (unsigned long long)sacc_[q]);
+#endif
 }
 
 // POSEHIP_STEM_KERNEL=0: the halo kernel's stem form everywhere (A/B runs, and the bit-equality test of the two)
@@ -391,6 +423,7 @@ static bool stem512_enabled() {  // (read at every build / launch: the test swit
 // The persistent stem kernel serves the shape it is built for; everything else stays on the halo kernel's stem form.
 bool ph_stem512_applies(const PhConvParams& p) {
   return stem512_enabled() && p.stem && p.pool && p.cout == 64 && p.cin_read == 64 && p.Kpad == 576 && p.Kpad0 >= 96 &&
+         p.cin0_span <= 4 &&   // (the kernel stages channels 0..3 of the frame pixels)
          p.n_dst >= 1 && p.tile_ctr && !(p.H & 1) && !(p.W & 1) &&
          (unsigned long long)p.B * p.dst[0].Hp * p.dst[0].Wp * p.dst[0].Cs < 0x3fffffffull &&
          (unsigned long long)p.NQ * 16ull < 0xffffffffull;
