@@ -26,10 +26,10 @@ eng.sync(); L.ph_debug_stem512_cycles(cyc, 1)
 ms = eng.forward_timed(B); eng.sync(); L.ph_debug_stem512_cycles(cyc, 0)
 n = max(1, cyc[5])
 print("op ms", [round(m, 4) for m in ms], "tiles", n)
-names = ["P1 conv1_1 (+ frame wait, next loads issued)", "barrier A", "P2 K loop", "barrier B", "P3 pool + store"]
+names = ["P1 conv1_1 (frame pixels from LDS; rows stored, next loads issued)", "barrier A", "P2 K loop (+ next frame pixels -> LDS)", "barrier B", "P3 pool"]
 tot = sum(cyc[i] for i in range(5))
 for i, k in enumerate(names):
-    print(f"{k:48s} {cyc[i] / n:9.0f} cycles per tile  {100 * cyc[i] / tot:5.1f} %")
-print(f"{'sum':48s} {tot / n:9.0f}")
-for i, k in ((6, "P1: row block 0 (waits for the loads)"), (7, "P1: row blocks 1..4"), (8, "P1: previous rows stored"), (9, "P1: next tile number"), (10, "P1: 15 loads issued")):
-    print(f"  {k:46s} {cyc[i] / n:9.0f}")
+    print(f"{k:68s} {cyc[i] / n:9.0f} cycles per tile  {100 * cyc[i] / tot:5.1f} %")
+print(f"{'sum':68s} {tot / n:9.0f}")
+for i, k in ((6, "P1: row block 0"), (7, "P1: row blocks 1..4"), (8, "P1: next tile number (LDS), the one after (counter)"), (9, "P1: previous rows stored"), (10, "P1: next tile's 2 loads issued")):
+    print(f"  {k:66s} {cyc[i] / n:9.0f}")
