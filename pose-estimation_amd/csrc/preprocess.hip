@@ -87,7 +87,10 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ frames, int B, int
         }
         for (int k = 0; k < 4; k++) {
           const int xx = sx + (k & 1), yy = sy + (k >> 1);
-          if (xx >= 0 && xx < W0 && yy >= 0 && yy < H0) {
+          // (a tap of weight zero adds nothing and is not fetched: frames that already have the net size -- phase
+          // 0 in both directions -- read 2 source pixels instead of 4; the kernel is bound by the number of its
+          // byte loads, not by their bytes)
+          if (w[k] != 0 && xx >= 0 && xx < W0 && yy >= 0 && yy < H0) {
             const uint8_t* p = img + ((size_t)yy * W0 + xx) * 3;
             for (int c = 0; c < 3; c++) acc[c] += (int)p[c] * w[k];
           }
