@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Prints a hash of the network output of a few graphs with 96-channel 3x3 layers (and of the full BODY_25 graph), for
-comparing builds / switches across processes (the conv switches are read once per process):
+"""Prints a hash of the network output of a few graphs with 96- and 128-channel 3x3 layers (and of the full BODY_25
+graph), for comparing builds / switches across processes (the conv switches are read once per process):
 
-    for e in "" POSEHIP_NO_SPLIT=1 POSEHIP_NO_LIN=1; do env $e python tools/split_check.py; done
+    for e in X=1 POSEHIP_NO_LIN=1; do env $e python tools/split_check.py; done
 
-The three lines must be identical: the branch-free K loop, its weight / patch fetcher split for 96 channels and the
-generic loop accumulate in the same order."""
+The lines must be identical: the branch-free K loop and the generic loop accumulate in the same order.  (Written for the
+weight / patch fetcher split of the 96-channel instantiation, DESIGN 9: equal hashes, no gain, removed.)"""
 import hashlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pose-estimation_amd"))
