@@ -1460,6 +1460,12 @@ int ph_launch_decode_v2(const float* net_out, int C, int hs, int ws, int Ht, int
   // ranges per limb in the scoring kernel: enough blocks to level a few heavy limbs out over the chip
   int paf_sub = 4096 / (m.n_pairs * B > 0 ? m.n_pairs * B : 1);
   paf_sub = paf_sub < 1 ? 1 : (paf_sub > 8 ? 8 : paf_sub);
+  static const int paf_sub_env = [] {  // A/B override (1..8), anything else is ignored
+    const char* e = getenv("POSEHIP_PAF_SUB");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 8 ? v : 0;
+  }();
+  if (paf_sub_env) paf_sub = paf_sub_env;
   const size_t lim = 160 * 1024 - 1024;
   const bool paf_coef = !paf_raw && lds2_rest + (size_t)2 * hs * ws * 16 <= lim;
   const size_t lds2 = lds2_rest + (size_t)2 * hs * ws * (paf_coef ? 16 : 4);
